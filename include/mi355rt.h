@@ -1,0 +1,242 @@
+/*
+ * mi355rt.h -- C ABI of the MI355X-native replacement for the per-ray
+ * intersection + shading hot path of DarkAce65/raytracer.
+ *
+ * The reference has no FFI layer.  The seam this library replaces is the body
+ * of RaytracingScene::raytrace_to_image (src/render/raytracing_scene.rs:703-776),
+ * i.e. the `indexes.par_iter().for_each(process_pixel)` loop at :734-744 whose
+ * unit of work is `screen_raycast(x, y)` (:598-622).  A Rust host would flatten
+ * its private RaytracingScene fields (:45-51) into an `rt_scene_desc`, call
+ * `rt_scene_create` once after `Scene::build_raytracing_scene`
+ * (src/render/scene.rs:76-97) and `rt_render` once per frame instead of
+ * `screen_raycast` once per pixel.  See INTEGRATION.md for the binding sketch.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success or a negative RT_ERR_* code and
+ *     never unwinds or aborts across the boundary (the reference panics);
+ *     `rt_last_error()` returns a thread-local message for the last failure.
+ *   - plain pointers and sizes only.  The caller keeps ownership of every
+ *     array in `rt_scene_desc`; the library copies what it needs.
+ *   - matrices are row-major.  `world` / `inv_world` are 3x4 affine blocks
+ *     (12 doubles, rows of [r0 r1 r2 t]).
+ *   - primitive order in the descriptor IS the primitive-ID order
+ *     (= index in the Vec built by RaytracingScene::from_scene before the
+ *     bounded/unbounded partition, src/render/scene.rs:84-87,
+ *     src/core/bounds.rs:256-263).
+ *   - a handle is used by one host thread at a time.
+ */
+#ifndef MI355RT_H
+#define MI355RT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)   /* bad argument / malformed descriptor          */
+#define RT_ERR_UNSUPPORTED (-2) /* reference would panic (e.g. max_depth > 6) */
+#define RT_ERR_DEVICE (-3)    /* HIP runtime failure                          */
+#define RT_ERR_NOMEM (-4)     /* pool budget too small for one camera ray     */
+#define RT_ERR_IO (-5)        /* host loader: file / parse error              */
+
+#define RT_PRIM_SPHERE 0u   /* src/primitives/sphere.rs   */
+#define RT_PRIM_CUBE 1u     /* src/primitives/cube.rs     */
+#define RT_PRIM_PLANE 2u    /* src/primitives/plane.rs    */
+#define RT_PRIM_TRIANGLE 3u /* src/primitives/triangle.rs */
+
+#define RT_MAT_PHONG 0u    /* src/core/material.rs:22-47 */
+#define RT_MAT_PHYSICAL 1u /* src/core/material.rs:60-89 */
+
+#define RT_SIDE_BOTH 0u /* src/core/material.rs:9-20 (default Front) */
+#define RT_SIDE_FRONT 1u
+#define RT_SIDE_BACK 2u
+
+#define RT_LIGHT_AMBIENT 0u /* src/lights/ambient.rs */
+#define RT_LIGHT_POINT 1u   /* src/lights/point.rs   */
+
+#define RT_NO_HIT 0xFFFFFFFFu
+
+/* RenderOptions, src/render/mod.rs:133-159 (widths widened to u32). */
+typedef struct rt_render_options {
+    uint32_t width, height;
+    uint32_t max_depth;             /* u8 in the reference  */
+    uint32_t samples_per_pixel;     /* u16                  */
+    uint32_t max_reflected_rays;    /* u16                  */
+    uint32_t max_illumination_rays; /* u16                  */
+    double max_occlusion_distance;
+} rt_render_options;
+
+/* RaytracingCamera, src/render/raytracing_scene.rs:25-42.  cam_to_world is the
+ * upper-left 3x3 of look_at_rh(position,target,up).transpose() (row-major). */
+typedef struct rt_camera {
+    double fov_deg;
+    double position[3];
+    double cam_to_world[9];
+} rt_camera;
+
+/* Material::{Phong,Physical}, src/core/material.rs:22-107. */
+typedef struct rt_material {
+    uint32_t kind; /* RT_MAT_*  */
+    uint32_t side; /* RT_SIDE_* */
+    double color[3];
+    double emissive[3];
+    double specular[3];     /* phong    */
+    double reflectivity;    /* phong    */
+    double shininess;       /* phong    */
+    double opacity;         /* physical */
+    double roughness;       /* physical */
+    double metalness;       /* physical */
+    double refractive_index; /* physical */
+    int32_t texture_id;     /* -1: none */
+    uint32_t _pad;
+} rt_material;
+
+/* Light::{Ambient,Point}, src/lights/{ambient,point}.rs.  position = transform x origin
+ * (src/core/transform.rs:11-13). */
+typedef struct rt_light {
+    uint32_t kind; /* RT_LIGHT_* */
+    uint32_t _pad;
+    double color[3];
+    double intensity;
+    double position[3];
+} rt_light;
+
+/* Texture (decoded to RGB8, row 0 = top), src/core/texture.rs:8-44. */
+typedef struct rt_texture {
+    uint32_t width, height;
+    const uint8_t *rgb8; /* width*height*3 bytes */
+} rt_texture;
+
+typedef struct rt_scene_desc {
+    rt_render_options opts;
+    rt_camera camera;
+
+    /* flattened primitives, in primitive-ID order */
+    uint32_t n_prims;
+    uint32_t _pad0;
+    const uint8_t *prim_type;       /* [n_prims] RT_PRIM_*                       */
+    const uint32_t *prim_material;  /* [n_prims] index into materials            */
+    const uint32_t *prim_transform; /* [n_prims] index into world / inv_world    */
+    const double *prim_param;       /* [n_prims] sphere radius | cube size | 0   */
+    const double *prim_normal;      /* [n_prims*3] plane normal (as deserialised,
+                                       NOT normalised), zeros otherwise          */
+    const uint32_t *prim_tri;       /* [n_prims] triangle index or RT_NO_HIT     */
+
+    /* world transforms (parent*child already baked, flatten_to_world) */
+    uint32_t n_transforms;
+    uint32_t _pad1;
+    const double *world;     /* [n_transforms*12] */
+    const double *inv_world; /* [n_transforms*12] */
+
+    /* triangle vertex data in OBJECT space (src/primitives/triangle.rs:148-152) */
+    uint32_t n_tris;
+    uint32_t _pad2;
+    const double *tri_pos; /* [n_tris*9] p0 p1 p2          */
+    const double *tri_nrm; /* [n_tris*9] unit n0 n1 n2     */
+    const double *tri_uv;  /* [n_tris*6] uv0 uv1 uv2       */
+
+    uint32_t n_materials;
+    uint32_t n_lights;
+    const rt_material *materials;
+    const rt_light *lights;
+
+    uint32_t n_textures;
+    uint32_t _pad3;
+    const rt_texture *textures;
+} rt_scene_desc;
+
+/* What one call renders.  Pixels of the window [x0,x1) x [y0,y1), samples
+ * [s0,s1) of each pixel (global sample indices: sample 0 is the pixel centre,
+ * src/render/raytracing_scene.rs:560).  With shard_count > 1 only the
+ * tile_size x tile_size tiles assigned to `shard_index` (scattered order) are
+ * rendered; the other pixels of the output are left untouched.  All-zero
+ * window / sample fields mean "whole image, all samples". */
+typedef struct rt_render_params {
+    uint64_t seed;
+    uint32_t x0, y0, x1, y1;
+    uint32_t s0, s1;
+    uint32_t tile_size;   /* 0 -> 32 */
+    uint32_t shard_index; /* rank    */
+    uint32_t shard_count; /* 0/1 -> everything */
+    uint32_t flags;       /* RT_FLAG_* */
+} rt_render_params;
+
+#define RT_FLAG_COUNT_WORK 1u /* also count BVH nodes visited / primitives tested */
+
+/* Per-call measurements, filled by rt_render* when `stats` is non-NULL.
+ * Kernel times are HIP-event times on the stream the kernels ran on. */
+typedef struct rt_render_stats {
+    uint64_t ray_count;        /* reference counting rule, CastStats.ray_count */
+    uint64_t closest_rays;     /* get_color + get_illumination rays            */
+    uint64_t shadow_rays;
+    uint64_t camera_rays;
+    uint64_t nodes_visited_closest, prims_tested_closest; /* RT_FLAG_COUNT_WORK */
+    uint64_t nodes_visited_shadow, prims_tested_shadow;
+    uint32_t batches;
+    uint32_t launches_closest, launches_shadow, launches_other;
+    float ms_total;   /* whole call, first launch to last            */
+    float ms_raygen;  /* camera-ray generation                       */
+    float ms_closest; /* closest-hit traversal kernels               */
+    float ms_shadow;  /* any-hit traversal kernels                   */
+    float ms_expand;  /* shade/expand (child + shadow ray emission)  */
+    float ms_resolve; /* bottom-up shading resolve                   */
+    float ms_accum;   /* per-pixel accumulate                        */
+    uint32_t _pad;
+} rt_render_stats;
+
+typedef struct rt_scene rt_scene; /* opaque */
+
+/* Replaces Scene::build_raytracing_scene / KdTreeAccelerator::new
+ * (src/render/scene.rs:76-97, src/core/bounds.rs:255-296): validates and copies
+ * the descriptor, builds and linearises a BVH on the host, uploads everything
+ * to the current HIP device.  Fails with RT_ERR_DEVICE when no GPU is usable. */
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+
+/* Limit the device memory used for wavefront pools (default 8 GiB). */
+int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes);
+
+/* Replaces the pixel loop of raytrace_to_image
+ * (src/render/raytracing_scene.rs:727-746): accumulates, per rendered pixel,
+ * sum over samples of clamp(get_color(sample)) (:605-612) into
+ * d_rgb_accum[(y*width+x)*3 + c] (DEVICE pointer, doubles, += semantics) and
+ * adds the number of rays cast to *ray_count (HOST pointer, may be NULL).
+ * `stream` is a hipStream_t (NULL = the default stream).  Blocking. */
+int rt_render_device(rt_scene *scene, const rt_render_params *params, double *d_rgb_accum,
+                     uint64_t *ray_count, rt_render_stats *stats, void *stream);
+
+/* Replaces :614-621 + :757-769: colour = accum / spp, clamp, ^(1/2.2),
+ * (c*255.0) as u8, alpha 255.  Both pointers are DEVICE pointers. */
+int rt_tonemap_device(rt_scene *scene, const double *d_rgb_accum, uint8_t *d_rgba8, void *stream);
+
+/* Host-pointer convenience: zero-initialised accumulation, render, tonemap,
+ * copy back.  rgb_accum (w*h*3 doubles) and rgba8 (w*h*4 bytes) may be NULL. */
+int rt_render(rt_scene *scene, const rt_render_params *params, double *rgb_accum, uint8_t *rgba8,
+              uint64_t *ray_count, rt_render_stats *stats);
+
+/* Parity AOVs: closest hit of the pixel-centre camera ray of every pixel
+ * (get_color's raycast + compute_data, :531-532).  HOST pointers, w*h entries
+ * (normal: w*h*3); prim_id = RT_NO_HIT on a miss. */
+int rt_query_primary(rt_scene *scene, uint32_t *prim_id, double *t, double *normal3);
+
+/* Traversal-only probes used by the parity tests: n world-space rays
+ * (HOST pointers, origin/dir n*3 doubles).  shadow == 0: closest hit
+ * (KdTreeAccelerator::raycast, bounds.rs:302-308; ray_type Secondary);
+ * shadow != 0: any hit within tmax[i] (shadow_cast, bounds.rs:310-316),
+ * prim_id[i] = 1 if occluded else 0. */
+int rt_trace_rays(rt_scene *scene, uint32_t n, const double *origin, const double *dir,
+                  const double *tmax, int shadow, uint32_t *prim_id, double *t);
+
+/* BVH facts for reports: node count, leaf count, max depth, bytes resident. */
+int rt_scene_info(rt_scene *scene, uint64_t *out8);
+
+const char *rt_last_error(void);
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355RT_H */
