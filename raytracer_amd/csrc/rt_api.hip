@@ -1,0 +1,784 @@
+// rt_api.hip -- C ABI of libmi355rt.so (include/mi355rt.h): scene upload,
+// batch orchestration of the wavefront kernels, parity probes.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rt_bvh.h"
+#include "rt_internal.h"
+#include "rt_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+    } while (0)
+
+using namespace rt;
+
+// BoundingVolume::from_bounds_and_transform (bounds.rs:40-72): AABB of the 8
+// transformed corners, corner order x-major, f64::min / f64::max.
+Aabb world_aabb(const double mn[3], const double mx[3], const double *w) {
+    Aabb out{};
+    bool first = true;
+    const double xs[2] = {mn[0], mx[0]}, ys[2] = {mn[1], mx[1]}, zs[2] = {mn[2], mx[2]};
+    for (double x : xs)
+        for (double y : ys)
+            for (double z : zs) {
+                double p[3] = {w[0] * x + w[1] * y + w[2] * z + w[3], w[4] * x + w[5] * y + w[6] * z + w[7],
+                               w[8] * x + w[9] * y + w[10] * z + w[11]};
+                for (int k = 0; k < 3; ++k) {
+                    if (first) {
+                        out.mn[k] = out.mx[k] = p[k];
+                    } else {
+                        out.mn[k] = std::fmin(out.mn[k], p[k]);
+                        out.mx[k] = std::fmax(out.mx[k], p[k]);
+                    }
+                }
+                first = false;
+            }
+    return out;
+}
+
+// Rotation3::rotation_between(normal, +y) rows 0 and 2 (plane.rs:138-141).
+// Returns false where the reference's unwrap() panics (normal anti-parallel to +y).
+bool plane_uv_rotation(const double n[3], double rows[6]) {
+    const double ident[6] = {1, 0, 0, 0, 0, 1};
+    double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!(len > 0.0)) {
+        std::memcpy(rows, ident, sizeof(ident));
+        return true;
+    }
+    double a[3] = {n[0] / len, n[1] / len, n[2] / len};
+    // c = a x (0,1,0)
+    double c[3] = {a[1] * 0.0 - a[2] * 1.0, a[2] * 0.0 - a[0] * 0.0, a[0] * 1.0 - a[1] * 0.0};
+    double cl = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    double cosang = a[0] * 0.0 + a[1] * 1.0 + a[2] * 0.0;
+    if (cl > F64_EPS) {
+        double ax[3] = {c[0] / cl, c[1] / cl, c[2] / cl};
+        double angle = std::acos(cosang);
+        if (angle == 0.0) {
+            std::memcpy(rows, ident, sizeof(ident));
+            return true;
+        }
+        double s = std::sin(angle), co = std::cos(angle), omc = 1.0 - co;
+        double sqx = ax[0] * ax[0], sqz = ax[2] * ax[2];
+        rows[0] = sqx + (1.0 - sqx) * co;
+        rows[1] = ax[0] * ax[1] * omc - ax[2] * s;
+        rows[2] = ax[0] * ax[2] * omc + ax[1] * s;
+        rows[3] = ax[0] * ax[2] * omc - ax[1] * s;
+        rows[4] = ax[1] * ax[2] * omc + ax[0] * s;
+        rows[5] = sqz + (1.0 - sqz) * co;
+        return true;
+    }
+    if (cosang < 0.0) return false;
+    std::memcpy(rows, ident, sizeof(ident));
+    return true;
+}
+
+template <typename T>
+int upload(const std::vector<T> &host, const T **dev, std::vector<void *> &allocs, uint64_t *bytes) {
+    *dev = nullptr;
+    if (host.empty()) return RT_OK;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, host.size() * sizeof(T)));
+    allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<const T *>(p);
+    *bytes += host.size() * sizeof(T);
+    return RT_OK;
+}
+
+uint32_t morton2(uint32_t x, uint32_t y) {
+    auto spread = [](uint32_t v) {
+        v &= 0xFFFFu;
+        v = (v | (v << 8)) & 0x00FF00FFu;
+        v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1);
+}
+
+struct EventTimer {
+    // accumulates elapsed ms per kernel class from (start, stop) event pairs
+    struct Span {
+        hipEvent_t a, b;
+        int cls;
+    };
+    std::vector<Span> spans;
+    bool enabled = false;
+    hipStream_t stream = nullptr;
+    void begin(int cls) {
+        if (!enabled) return;
+        Span s{};
+        s.cls = cls;
+        hipEventCreate(&s.a);
+        hipEventCreate(&s.b);
+        hipEventRecord(s.a, stream);
+        spans.push_back(s);
+    }
+    void end() {
+        if (!enabled) return;
+        hipEventRecord(spans.back().b, stream);
+    }
+    void collect(float *per_class, uint32_t *launches, int n_classes) {
+        for (Span &s : spans) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess && s.cls < n_classes) {
+                per_class[s.cls] += ms;
+                launches[s.cls] += 1;
+            }
+            hipEventDestroy(s.a);
+            hipEventDestroy(s.b);
+        }
+        spans.clear();
+    }
+};
+
+enum { CLS_RAYGEN = 0, CLS_CLOSEST, CLS_SHADOW, CLS_EXPAND, CLS_RESOLVE, CLS_ACCUM, CLS_MISC, CLS_COUNT };
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    SceneDev dev{};
+    std::vector<void *> allocs;
+    uint64_t scene_bytes = 0;
+    uint64_t n_nodes = 0, n_leaves = 0, bvh_depth = 0;
+    int n_cus = 256;
+
+    uint64_t pool_bytes = 8ull << 30;
+    void *pool_mem = nullptr;
+    uint64_t pool_mem_bytes = 0;
+    NodePool np{};
+    ShadowPool sp{};
+    Counters *d_ctr = nullptr;
+    Counters *h_ctr = nullptr;  // pinned
+    uint32_t *d_tiles = nullptr;
+    uint32_t d_tiles_cap = 0;
+    double est_nodes_per_item = 0.0, est_shadows_per_item = 0.0;
+
+    ~rt_scene() {
+        for (void *p : allocs) hipFree(p);
+        if (pool_mem) hipFree(pool_mem);
+        if (d_ctr) hipFree(d_ctr);
+        if (h_ctr) hipHostFree(h_ctr);
+        if (d_tiles) hipFree(d_tiles);
+    }
+};
+
+namespace {
+
+int ensure_pools(rt_scene *s) {
+    if (s->pool_mem && s->pool_mem_bytes == s->pool_bytes) return RT_OK;
+    if (s->pool_mem) {
+        hipFree(s->pool_mem);
+        s->pool_mem = nullptr;
+    }
+    // bytes per node: ray 64 + hit 28 + info 16; per shadow ray: 34; shadow capacity = nodes / 2
+    const uint64_t per_node = 108, per_shadow = 34;
+    uint64_t cap = s->pool_bytes / (per_node + per_shadow / 2 + 8);
+    cap = std::min<uint64_t>(cap, 1ull << 31);
+    cap &= ~uint64_t(255);
+    if (cap < 4096) return fail(RT_ERR_NOMEM, "pool budget too small");
+    uint64_t scap = (cap / 2) & ~uint64_t(255);
+    HIP_TRY(hipMalloc(&s->pool_mem, s->pool_bytes));
+    s->pool_mem_bytes = s->pool_bytes;
+    char *p = static_cast<char *>(s->pool_mem);
+    auto take = [&](uint64_t bytes) {
+        char *r = p;
+        p += (bytes + 255) & ~uint64_t(255);
+        return r;
+    };
+    NodePool &np = s->np;
+    np.ox = reinterpret_cast<double *>(take(cap * 8));
+    np.oy = reinterpret_cast<double *>(take(cap * 8));
+    np.oz = reinterpret_cast<double *>(take(cap * 8));
+    np.dx = reinterpret_cast<double *>(take(cap * 8));
+    np.dy = reinterpret_cast<double *>(take(cap * 8));
+    np.dz = reinterpret_cast<double *>(take(cap * 8));
+    np.path = reinterpret_cast<uint64_t *>(take(cap * 8));
+    np.t = reinterpret_cast<double *>(take(cap * 8));
+    np.bu = reinterpret_cast<double *>(take(cap * 8));
+    np.bv = reinterpret_cast<double *>(take(cap * 8));
+    np.root = reinterpret_cast<uint32_t *>(take(cap * 4));
+    np.meta = reinterpret_cast<uint32_t *>(take(cap * 4));
+    np.prim = reinterpret_cast<uint32_t *>(take(cap * 4));
+    np.first_child = reinterpret_cast<uint32_t *>(take(cap * 4));
+    np.first_shadow = reinterpret_cast<uint32_t *>(take(cap * 4));
+    np.counts = reinterpret_cast<uint32_t *>(take(cap * 4));
+    np.light_mask = reinterpret_cast<uint32_t *>(take(cap * 4));
+    np.capacity = static_cast<uint32_t>(cap);
+    ShadowPool &sp = s->sp;
+    sp.dx = reinterpret_cast<double *>(take(scap * 8));
+    sp.dy = reinterpret_cast<double *>(take(scap * 8));
+    sp.dz = reinterpret_cast<double *>(take(scap * 8));
+    sp.tmax = reinterpret_cast<double *>(take(scap * 8));
+    sp.light = reinterpret_cast<uint8_t *>(take(scap));
+    sp.occluded = reinterpret_cast<uint8_t *>(take(scap));
+    sp.capacity = static_cast<uint32_t>(scap);
+    if (static_cast<uint64_t>(p - static_cast<char *>(s->pool_mem)) > s->pool_bytes)
+        return fail(RT_ERR_NOMEM, "internal: pool carve exceeds budget");
+    if (!s->d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ctr), sizeof(Counters)));
+    if (!s->h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctr), sizeof(Counters)));
+    s->est_nodes_per_item = s->est_shadows_per_item = 0.0;
+    return RT_OK;
+}
+
+struct CallPlan {
+    WorkList wl{};
+    uint64_t total_items = 0;
+};
+
+// Tiles of the call, uploaded to d_tiles.  Unsharded: one tile = the window.
+int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStream_t stream) {
+    const rt_render_options &o = s->dev.opts;
+    rt_render_params p{};
+    if (prm) p = *prm;
+    uint32_t x0 = p.x0, y0 = p.y0, x1 = p.x1, y1 = p.y1, s0 = p.s0, s1 = p.s1;
+    if (x1 == 0 && y1 == 0) {
+        x0 = y0 = 0;
+        x1 = o.width;
+        y1 = o.height;
+    }
+    if (s1 == 0) {
+        s0 = 0;
+        s1 = o.samples_per_pixel;
+    }
+    if (x1 > o.width || y1 > o.height || x0 >= x1 || y0 >= y1 || s0 >= s1 || s1 > o.samples_per_pixel)
+        return fail(RT_ERR_INVALID, "render window / sample range out of range");
+    std::vector<uint32_t> tiles;
+    WorkList &wl = plan->wl;
+    if (p.shard_count <= 1) {
+        tiles = {x0, y0};
+        wl.tile_w = x1 - x0;
+        wl.tile_h = y1 - y0;
+    } else {
+        if (p.shard_index >= p.shard_count) return fail(RT_ERR_INVALID, "shard_index >= shard_count");
+        const uint32_t ts = p.tile_size ? p.tile_size : 32u;
+        const uint32_t tx0 = x0 / ts, ty0 = y0 / ts, tx1 = (x1 + ts - 1) / ts, ty1 = (y1 + ts - 1) / ts;
+        std::vector<std::pair<uint32_t, uint32_t>> keyed;  // (morton, packed xy)
+        for (uint32_t ty = ty0; ty < ty1; ++ty)
+            for (uint32_t tx = tx0; tx < tx1; ++tx) {
+                if (tx > 0xFFFF || ty > 0xFFFF) return fail(RT_ERR_INVALID, "too many tiles");
+                keyed.emplace_back(morton2(tx, ty), (ty << 16) | tx);
+            }
+        std::sort(keyed.begin(), keyed.end());
+        for (size_t j = 0; j < keyed.size(); ++j)
+            if (j % p.shard_count == p.shard_index) {
+                tiles.push_back((keyed[j].second & 0xFFFFu) * ts);
+                tiles.push_back((keyed[j].second >> 16) * ts);
+            }
+        wl.tile_w = wl.tile_h = ts;
+    }
+    wl.n_tiles = static_cast<uint32_t>(tiles.size() / 2);
+    wl.x0 = x0;
+    wl.y0 = y0;
+    wl.x1 = x1;
+    wl.y1 = y1;
+    wl.s0 = s0;
+    wl.ns = s1 - s0;
+    wl.seed = p.seed;
+    plan->total_items = static_cast<uint64_t>(wl.n_tiles) * wl.tile_w * wl.tile_h * wl.ns;
+    if (plan->total_items > 0xFFFFFFFFull) return fail(RT_ERR_INVALID, "more than 2^32 camera rays in one call");
+    if (wl.n_tiles > s->d_tiles_cap) {
+        if (s->d_tiles) hipFree(s->d_tiles);
+        s->d_tiles = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_tiles), tiles.size() * sizeof(uint32_t)));
+        s->d_tiles_cap = wl.n_tiles;
+    }
+    if (wl.n_tiles) {
+        HIP_TRY(hipMemcpyAsync(s->d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));  // `tiles` is a local
+    }
+    wl.tile_xy = s->d_tiles;
+    return RT_OK;
+}
+
+uint32_t grid_for(const rt_scene *s, uint64_t n, uint32_t blocks_per_cu) {
+    uint64_t need = (n + BLOCK - 1) / BLOCK;
+    uint64_t cap = static_cast<uint64_t>(s->n_cus) * blocks_per_cu;
+    return static_cast<uint32_t>(std::max<uint64_t>(1, std::min(need, cap)));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+const char *rt_version(void) { return "mi355rt 0.1 (gfx950, f64 wavefront)"; }
+
+int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
+    if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const rt_render_options &o = d->opts;
+    if (o.width == 0 || o.height == 0 || o.samples_per_pixel == 0)
+        return fail(RT_ERR_INVALID, "width, height and samples_per_pixel must be positive");
+    if (static_cast<uint64_t>(o.width) * o.height > 0x7FFFFFFFull) return fail(RT_ERR_INVALID, "image too large");
+    if (o.max_depth > 6)  // 8_u16.pow(depth) overflows in the reference for depth >= 6 (divide by zero)
+        return fail(RT_ERR_UNSUPPORTED, "max_depth > 6: 8_u16.pow(depth) overflows in the reference");
+    if (o.samples_per_pixel > 65535 || o.max_reflected_rays > 65535 || o.max_illumination_rays > 65535)
+        return fail(RT_ERR_INVALID, "u16 option out of range");
+    if (d->n_lights > 255) return fail(RT_ERR_UNSUPPORTED, "more than 255 lights");
+    if (d->n_materials >= (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "too many materials");
+    uint32_t n_point = 0;
+    for (uint32_t i = 0; i < d->n_lights; ++i) n_point += d->lights[i].kind == RT_LIGHT_POINT ? 1u : 0u;
+    if (n_point > 32) return fail(RT_ERR_UNSUPPORTED, "more than 32 point lights");
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const rt_material &m = d->materials[i];
+        if (m.kind > RT_MAT_PHYSICAL || m.side > RT_SIDE_BACK) return fail(RT_ERR_INVALID, "bad material kind/side");
+        if (m.texture_id >= static_cast<int32_t>(d->n_textures)) return fail(RT_ERR_INVALID, "texture_id out of range");
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(RT_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+    auto sc = std::make_unique<rt_scene>();
+    HIP_TRY(hipGetDevice(&sc->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
+    sc->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    // ---- flatten primitives
+    std::vector<ShadePrim> shade(d->n_prims);
+    std::vector<PlanePrim> planes;
+    std::vector<Aabb> boxes;
+    std::vector<uint32_t> bounded_ids;
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const uint32_t type = d->prim_type[i];
+        if (type > RT_PRIM_TRIANGLE) return fail(RT_ERR_INVALID, "bad primitive type");
+        if (d->prim_material[i] >= d->n_materials || d->prim_transform[i] >= d->n_transforms)
+            return fail(RT_ERR_INVALID, "primitive references out of range");
+        if (d->prim_transform[i] >= (1u << 28)) return fail(RT_ERR_UNSUPPORTED, "too many transforms");
+        ShadePrim &sh = shade[i];
+        std::memset(&sh, 0, sizeof(sh));
+        sh.type = type;
+        sh.material = d->prim_material[i];
+        sh.xf = d->prim_transform[i];
+        sh.tri = 0;
+        sh.param = d->prim_param[i];
+        sh.uv_ok = 1;
+        const rt_material &m = d->materials[sh.material];
+        const uint32_t meta = type | (m.side << 2) | (sh.xf << 4);
+        const double *w = d->world + 12ull * sh.xf;
+        if (type == RT_PRIM_PLANE) {
+            for (int k = 0; k < 3; ++k) sh.normal[k] = d->prim_normal[3ull * i + k];
+            sh.uv_ok = plane_uv_rotation(sh.normal, sh.uv_rot) ? 1u : 0u;
+            PlanePrim pp{};
+            for (int k = 0; k < 3; ++k) pp.normal[k] = sh.normal[k];
+            pp.prim_id = i;
+            pp.meta = meta;
+            planes.push_back(pp);
+            continue;
+        }
+        double mn[3], mx[3];
+        if (type == RT_PRIM_SPHERE) {  // sphere.rs:133-141
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = -sh.param;
+                mx[k] = sh.param;
+            }
+        } else if (type == RT_PRIM_CUBE) {  // cube.rs:177-186
+            double h = sh.param / 2.0;
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = -h;
+                mx[k] = h;
+            }
+        } else {  // triangle.rs:235-251
+            uint32_t t = d->prim_tri[i];
+            if (t >= d->n_tris) return fail(RT_ERR_INVALID, "triangle index out of range");
+            sh.tri = t;
+            const double *p = d->tri_pos + 9ull * t;
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = mx[k] = p[k];
+                for (int v = 1; v < 3; ++v) {
+                    mn[k] = std::fmin(mn[k], p[3 * v + k]);
+                    mx[k] = std::fmax(mx[k], p[3 * v + k]);
+                }
+            }
+        }
+        boxes.push_back(world_aabb(mn, mx, w));
+        bounded_ids.push_back(i);
+    }
+    if (bounded_ids.size() >= (1ull << 28)) return fail(RT_ERR_UNSUPPORTED, "too many bounded primitives");
+
+    // ---- BVH
+    BvhBuildResult bvh = build_bvh(boxes);
+    std::vector<LeafPrim> leaf(bvh.order.size());
+    for (size_t j = 0; j < bvh.order.size(); ++j) {
+        const uint32_t b = bvh.order[j], pid = bounded_ids[b];
+        LeafPrim &lp = leaf[j];
+        std::memset(&lp, 0, sizeof(lp));
+        for (int k = 0; k < 3; ++k) {
+            lp.bmin[k] = boxes[b].mn[k];
+            lp.bmax[k] = boxes[b].mx[k];
+        }
+        const ShadePrim &sh = shade[pid];
+        if (sh.type == RT_PRIM_TRIANGLE) std::memcpy(lp.geom, d->tri_pos + 9ull * sh.tri, 9 * sizeof(double));
+        else lp.geom[0] = sh.param;
+        lp.prim_id = pid;
+        lp.meta = sh.type | (d->materials[sh.material].side << 2) | (sh.xf << 4);
+    }
+    sc->n_nodes = bvh.nodes.size();
+    sc->n_leaves = bvh.n_leaves;
+    sc->bvh_depth = bvh.max_depth;
+
+    // ---- upload
+    SceneDev &dev = sc->dev;
+    dev.opts = o;
+    for (int k = 0; k < 3; ++k) dev.cam_pos[k] = d->camera.position[k];
+    for (int k = 0; k < 9; ++k) dev.cam_to_world[k] = d->camera.cam_to_world[k];
+    dev.fov_scale = std::tan(d->camera.fov_deg * (3.14159265358979323846 / 180.0) / 2.0);  // :82-84
+    dev.root_ref = bvh.root_ref;
+    dev.n_planes = static_cast<uint32_t>(planes.size());
+    dev.n_bounded = static_cast<uint32_t>(bounded_ids.size());
+    dev.n_prims = d->n_prims;
+    dev.scene_scale = 0.0;
+    if (!boxes.empty())
+        for (int k = 0; k < 3; ++k)
+            dev.scene_scale = std::fmax(dev.scene_scale, std::fmax(std::fabs(bvh.root_box.mn[k]), std::fabs(bvh.root_box.mx[k])));
+    dev.n_lights = d->n_lights;
+    dev.n_point_lights = n_point;
+
+    std::vector<double> inv(d->inv_world, d->inv_world + 12ull * d->n_transforms);
+    std::vector<double> tri_nrm(d->tri_nrm, d->tri_nrm + 9ull * d->n_tris);
+    std::vector<double> tri_uv(d->tri_uv, d->tri_uv + 6ull * d->n_tris);
+    std::vector<rt_material> mats(d->materials, d->materials + d->n_materials);
+    std::vector<DLight> lights(d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        lights[i].kind = d->lights[i].kind;
+        lights[i]._pad = 0;
+        for (int k = 0; k < 3; ++k) {
+            lights[i].color[k] = d->lights[i].color[k];
+            lights[i].position[k] = d->lights[i].position[k];
+        }
+        lights[i].intensity = d->lights[i].intensity;
+    }
+    std::vector<DTexture> texs(d->n_textures);
+    std::vector<uint8_t> texels;
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const rt_texture &t = d->textures[i];
+        if (t.width == 0 || t.height == 0 || !t.rgb8) return fail(RT_ERR_INVALID, "empty texture");
+        texs[i].width = t.width;
+        texs[i].height = t.height;
+        texs[i].offset = texels.size();
+        texels.insert(texels.end(), t.rgb8, t.rgb8 + static_cast<size_t>(t.width) * t.height * 3);
+    }
+    int rc;
+    uint64_t *bytes = &sc->scene_bytes;
+    if ((rc = upload(bvh.nodes, &dev.nodes, sc->allocs, bytes))) return rc;
+    if ((rc = upload(leaf, &dev.leaf_prims, sc->allocs, bytes))) return rc;
+    if ((rc = upload(planes, &dev.planes, sc->allocs, bytes))) return rc;
+    if ((rc = upload(shade, &dev.shade_prims, sc->allocs, bytes))) return rc;
+    if ((rc = upload(inv, &dev.inv_world, sc->allocs, bytes))) return rc;
+    if ((rc = upload(tri_nrm, &dev.tri_nrm, sc->allocs, bytes))) return rc;
+    if ((rc = upload(tri_uv, &dev.tri_uv, sc->allocs, bytes))) return rc;
+    if ((rc = upload(mats, &dev.materials, sc->allocs, bytes))) return rc;
+    if ((rc = upload(lights, &dev.lights, sc->allocs, bytes))) return rc;
+    if ((rc = upload(texs, &dev.textures, sc->allocs, bytes))) return rc;
+    if ((rc = upload(texels, &dev.texels, sc->allocs, bytes))) return rc;
+    *out = sc.release();
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene *scene) { delete scene; }
+
+int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes) {
+    if (!scene) return fail(RT_ERR_INVALID, "null scene");
+    if (bytes < (1ull << 20)) return fail(RT_ERR_INVALID, "pool budget below 1 MiB");
+    scene->pool_bytes = bytes;
+    return RT_OK;
+}
+
+int rt_scene_info(rt_scene *scene, uint64_t *out8) {
+    if (!scene || !out8) return fail(RT_ERR_INVALID, "null argument");
+    out8[0] = scene->n_nodes;
+    out8[1] = scene->n_leaves;
+    out8[2] = scene->bvh_depth;
+    out8[3] = scene->scene_bytes;
+    out8[4] = scene->dev.n_bounded;
+    out8[5] = scene->dev.n_planes;
+    out8[6] = scene->np.capacity;
+    out8[7] = scene->sp.capacity;
+    return RT_OK;
+}
+
+int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_accum, uint64_t *ray_count,
+                     rt_render_stats *stats, void *stream_v) {
+    if (!s || !d_rgb_accum) return fail(RT_ERR_INVALID, "null argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    int rc = ensure_pools(s);
+    if (rc) return rc;
+    CallPlan plan;
+    if ((rc = plan_call(s, params, &plan, stream))) return rc;
+    const WorkList &wl = plan.wl;
+    const bool count_work = params && (params->flags & RT_FLAG_COUNT_WORK);
+    const uint32_t max_depth = s->dev.opts.max_depth;
+    const NodePool &np = s->np;
+    const ShadowPool &sp = s->sp;
+
+    rt_render_stats st{};
+    EventTimer timer;
+    timer.enabled = stats != nullptr;
+    timer.stream = stream;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    if (stats) {
+        hipEventCreate(&ev_begin);
+        hipEventCreate(&ev_end);
+        hipEventRecord(ev_begin, stream);
+    }
+
+    uint64_t item0 = 0;
+    // first batch: modest guess, later batches sized from the measured expansion
+    uint64_t batch = std::min<uint64_t>(plan.total_items, std::max<uint64_t>(wl.ns, np.capacity / 96));
+    if (s->est_nodes_per_item > 0.0) {
+        double fit = std::min(np.capacity / s->est_nodes_per_item, sp.capacity / std::max(s->est_shadows_per_item, 1e-9));
+        batch = std::min<uint64_t>(plan.total_items, std::max<uint64_t>(wl.ns, static_cast<uint64_t>(0.7 * fit)));
+    }
+    const uint32_t gmax = static_cast<uint32_t>(s->n_cus) * 8u;
+    while (item0 < plan.total_items) {
+        uint64_t n = std::min<uint64_t>(batch, plan.total_items - item0);
+        n = std::min<uint64_t>(n, np.capacity);
+        n -= n % wl.ns;
+        if (n == 0) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's samples");
+        const uint32_t n32 = static_cast<uint32_t>(n), i0 = static_cast<uint32_t>(item0);
+
+        timer.begin(CLS_MISC);
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, stream, s->d_ctr, n32);
+        timer.end();
+        timer.begin(CLS_RAYGEN);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, s->d_ctr, i0, n32);
+        timer.end();
+        if (max_depth > 0) {
+            for (uint32_t level = 0; level < max_depth; ++level) {
+                const uint32_t g = level == 0 ? grid_for(s, n, 4) : static_cast<uint32_t>(s->n_cus) * 4u;
+                timer.begin(CLS_CLOSEST);
+                if (count_work) hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(BLOCK), 0, stream, s->dev, np, s->d_ctr, level);
+                else hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(BLOCK), 0, stream, s->dev, np, s->d_ctr, level);
+                timer.end();
+                timer.begin(CLS_EXPAND);
+                hipLaunchKernelGGL(k_expand, dim3(level == 0 ? grid_for(s, n, 8) : gmax), dim3(BLOCK), 0, stream, s->dev, wl, np, sp,
+                                   s->d_ctr, level);
+                hipLaunchKernelGGL(k_advance_level, dim3(1), dim3(64), 0, stream, s->d_ctr, level, np.capacity, sp.capacity);
+                timer.end();
+            }
+            timer.begin(CLS_SHADOW);
+            if (count_work)
+                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(static_cast<uint32_t>(s->n_cus) * 4u), dim3(BLOCK), 0, stream,
+                                   s->dev, np, sp, s->d_ctr, 0u);
+            else
+                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(static_cast<uint32_t>(s->n_cus) * 4u), dim3(BLOCK), 0, stream,
+                                   s->dev, np, sp, s->d_ctr, 0u);
+            timer.end();
+            for (uint32_t level = max_depth; level-- > 0;) {
+                timer.begin(CLS_RESOLVE);
+                hipLaunchKernelGGL(k_resolve, dim3(level == 0 ? grid_for(s, n, 8) : gmax), dim3(BLOCK), 0, stream, s->dev, np, sp,
+                                   s->d_ctr, level);
+                timer.end();
+            }
+            timer.begin(CLS_ACCUM);
+            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(s, n / wl.ns, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, s->d_ctr, i0,
+                               n32, d_rgb_accum);
+            timer.end();
+        }
+        HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipGetLastError());
+        const Counters &c = *s->h_ctr;
+        float cls_ms[CLS_COUNT] = {0};
+        uint32_t cls_n[CLS_COUNT] = {0};
+        timer.collect(cls_ms, cls_n, CLS_COUNT);
+        if (c.overflow) {
+            if (n <= wl.ns) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's ray tree");
+            batch = std::max<uint64_t>(wl.ns, (n / 2) - (n / 2) % wl.ns);
+            s->est_nodes_per_item = 0.0;
+            continue;  // re-run the same range with a smaller batch; nothing was accumulated
+        }
+        // ---- statistics (reference counting rule: +1 per traced get_color/get_illumination, +1 per shadow ray)
+        uint64_t closest = c.active_camera;
+        for (uint32_t l = 1; l <= max_depth && l <= MAX_LEVELS; ++l) closest += c.level_count[l];
+        if (max_depth == 0) closest = 0;
+        st.closest_rays += closest;
+        st.shadow_rays += c.shadow_alloc;
+        st.camera_rays += c.active_camera;
+        st.nodes_visited_closest += c.nodes_visited_closest;
+        st.prims_tested_closest += c.prims_tested_closest;
+        st.nodes_visited_shadow += c.nodes_visited_shadow;
+        st.prims_tested_shadow += c.prims_tested_shadow;
+        st.batches += 1;
+        st.ms_raygen += cls_ms[CLS_RAYGEN];
+        st.ms_closest += cls_ms[CLS_CLOSEST];
+        st.ms_shadow += cls_ms[CLS_SHADOW];
+        st.ms_expand += cls_ms[CLS_EXPAND];
+        st.ms_resolve += cls_ms[CLS_RESOLVE];
+        st.ms_accum += cls_ms[CLS_ACCUM];
+        st.launches_closest += cls_n[CLS_CLOSEST];
+        st.launches_shadow += cls_n[CLS_SHADOW];
+        st.launches_other += cls_n[CLS_RAYGEN] + cls_n[CLS_EXPAND] + cls_n[CLS_RESOLVE] + cls_n[CLS_ACCUM] + cls_n[CLS_MISC];
+
+        s->est_nodes_per_item = static_cast<double>(c.node_alloc) / static_cast<double>(n);
+        s->est_shadows_per_item = static_cast<double>(c.shadow_alloc) / static_cast<double>(n);
+        double fit = std::min(np.capacity / std::max(s->est_nodes_per_item, 1.0),
+                              sp.capacity / std::max(s->est_shadows_per_item, 1e-9));
+        batch = std::max<uint64_t>(wl.ns, static_cast<uint64_t>(0.7 * fit));
+        item0 += n;
+    }
+    st.ray_count = st.closest_rays + st.shadow_rays;
+    if (stats) {
+        hipEventRecord(ev_end, stream);
+        hipEventSynchronize(ev_end);
+        hipEventElapsedTime(&st.ms_total, ev_begin, ev_end);
+        hipEventDestroy(ev_begin);
+        hipEventDestroy(ev_end);
+        *stats = st;
+    }
+    if (ray_count) *ray_count += st.ray_count;
+    return RT_OK;
+}
+
+int rt_tonemap_device(rt_scene *s, const double *d_rgb_accum, uint8_t *d_rgba8, void *stream_v) {
+    if (!s || !d_rgb_accum || !d_rgba8) return fail(RT_ERR_INVALID, "null argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const uint32_t n = s->dev.opts.width * s->dev.opts.height;
+    hipLaunchKernelGGL(k_tonemap, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, stream, n, s->dev.opts.samples_per_pixel, d_rgb_accum,
+                       d_rgba8);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render(rt_scene *s, const rt_render_params *params, double *rgb_accum, uint8_t *rgba8, uint64_t *ray_count,
+              rt_render_stats *stats) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    const uint64_t n = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height;
+    double *d_acc = nullptr;
+    uint8_t *d_rgba = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_acc), n * 3 * sizeof(double)));
+    int rc = RT_OK;
+    do {
+        if (hipMemset(d_acc, 0, n * 3 * sizeof(double)) != hipSuccess) {
+            rc = fail(RT_ERR_DEVICE, "hipMemset failed");
+            break;
+        }
+        if ((rc = rt_render_device(s, params, d_acc, ray_count, stats, nullptr))) break;
+        if (rgb_accum && hipMemcpy(rgb_accum, d_acc, n * 3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = fail(RT_ERR_DEVICE, "copy of the accumulation buffer failed");
+            break;
+        }
+        if (rgba8) {
+            if (hipMalloc(reinterpret_cast<void **>(&d_rgba), n * 4) != hipSuccess) {
+                rc = fail(RT_ERR_DEVICE, "hipMalloc failed");
+                break;
+            }
+            if ((rc = rt_tonemap_device(s, d_acc, d_rgba, nullptr))) break;
+            if (hipMemcpy(rgba8, d_rgba, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                rc = fail(RT_ERR_DEVICE, "copy of the image failed");
+                break;
+            }
+        }
+    } while (false);
+    hipFree(d_acc);
+    if (d_rgba) hipFree(d_rgba);
+    return rc;
+}
+
+int rt_query_primary(rt_scene *s, uint32_t *prim_id, double *t, double *normal3) {
+    if (!s || !prim_id || !t || !normal3) return fail(RT_ERR_INVALID, "null argument");
+    int rc = ensure_pools(s);
+    if (rc) return rc;
+    rt_render_params prm{};
+    prm.s0 = 0;
+    prm.s1 = 1;
+    CallPlan plan;
+    if ((rc = plan_call(s, &prm, &plan, nullptr))) return rc;
+    const uint64_t npx = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height;
+    uint32_t *d_id = nullptr;
+    double *d_t = nullptr, *d_n = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_id), npx * 4));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_t), npx * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_n), npx * 24));
+    uint64_t item0 = 0;
+    while (item0 < plan.total_items) {
+        const uint32_t n = static_cast<uint32_t>(std::min<uint64_t>(plan.total_items - item0, s->np.capacity));
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, n);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, s->d_ctr,
+                           static_cast<uint32_t>(item0), n);
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, n, 4)), dim3(BLOCK), 0, nullptr, s->dev, s->np, s->d_ctr, 0u);
+        hipLaunchKernelGGL(k_primary_aov, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np,
+                           static_cast<uint32_t>(item0), n, d_id, d_t, d_n);
+        item0 += n;
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(prim_id, d_id, npx * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(t, d_t, npx * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(normal3, d_n, npx * 24, hipMemcpyDeviceToHost);
+    hipFree(d_id);
+    hipFree(d_t);
+    hipFree(d_n);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("rt_query_primary: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_trace_rays(rt_scene *s, uint32_t n, const double *origin, const double *dir, const double *tmax, int shadow,
+                  uint32_t *prim_id, double *t) {
+    if (!s || !origin || !dir || !prim_id || (shadow && !tmax)) return fail(RT_ERR_INVALID, "null argument");
+    int rc = ensure_pools(s);
+    if (rc) return rc;
+    const NodePool &np = s->np;
+    std::vector<double> col;
+    std::vector<uint32_t> meta;
+    uint32_t done = 0;
+    while (done < n) {
+        const uint32_t m = std::min<uint32_t>(n - done, np.capacity);
+        col.resize(m);
+        auto put = [&](double *dst, const double *src, int comp) -> hipError_t {
+            for (uint32_t i = 0; i < m; ++i) col[i] = src[3ull * (done + i) + comp];
+            return hipMemcpy(dst, col.data(), m * sizeof(double), hipMemcpyHostToDevice);
+        };
+        HIP_TRY(put(np.ox, origin, 0));
+        HIP_TRY(put(np.oy, origin, 1));
+        HIP_TRY(put(np.oz, origin, 2));
+        HIP_TRY(put(np.dx, dir, 0));
+        HIP_TRY(put(np.dy, dir, 1));
+        HIP_TRY(put(np.dz, dir, 2));
+        meta.assign(m, 1u);  // depth 1 secondary
+        HIP_TRY(hipMemcpy(np.meta, meta.data(), m * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, m);
+        if (shadow) {
+            HIP_TRY(hipMemcpy(np.t, tmax + done, m * sizeof(double), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid_for(s, m, 4)), dim3(BLOCK), 0, nullptr, s->dev, np, s->sp,
+                               s->d_ctr, m);
+        } else {
+            hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, m, 4)), dim3(BLOCK), 0, nullptr, s->dev, np, s->d_ctr, 0u);
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(prim_id + done, np.prim, m * 4, hipMemcpyDeviceToHost));
+        if (t) {
+            if (shadow) std::fill(t + done, t + done + m, 0.0);
+            else HIP_TRY(hipMemcpy(t + done, np.t, m * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        done += m;
+    }
+    if (t && !shadow)
+        for (uint32_t i = 0; i < n; ++i)
+            if (prim_id[i] == RT_NO_HIT) t[i] = 0.0;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+// Binned-SAH BVH2 builder (host).  The tree only accelerates: every bounded
+// primitive keeps its own exact world-AABB slab test in the kernels
+// (bounds.rs:172-181), node boxes are exact unions of those AABBs, and the
+// kernels test node boxes conservatively, so tree shape never changes results.
+#include "rt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace rt {
+namespace {
+
+constexpr int kBins = 16;
+constexpr double kIntersectCost = 3.0;  // one primitive test ~ three node visits (f64, 9 divisions)
+constexpr uint32_t kLeafTarget = 4;
+
+struct Builder {
+    const std::vector<Aabb> &boxes;
+    std::vector<uint32_t> order;
+    std::vector<double> cx, cy, cz;
+    BvhBuildResult out;
+
+    explicit Builder(const std::vector<Aabb> &b) : boxes(b) {}
+
+    static Aabb empty_box() {
+        const double inf = std::numeric_limits<double>::infinity();
+        return Aabb{{inf, inf, inf}, {-inf, -inf, -inf}};
+    }
+    static void grow(Aabb &a, const Aabb &b) {
+        for (int k = 0; k < 3; ++k) {
+            a.mn[k] = std::fmin(a.mn[k], b.mn[k]);
+            a.mx[k] = std::fmax(a.mx[k], b.mx[k]);
+        }
+    }
+    static double area(const Aabb &a) {
+        double dx = a.mx[0] - a.mn[0], dy = a.mx[1] - a.mn[1], dz = a.mx[2] - a.mn[2];
+        if (!(dx >= 0.0) || !(dy >= 0.0) || !(dz >= 0.0)) return 0.0;
+        return 2.0 * (dx * dy + dy * dz + dx * dz);
+    }
+    double centroid(uint32_t prim, int axis) const { return axis == 0 ? cx[prim] : (axis == 1 ? cy[prim] : cz[prim]); }
+
+    static uint32_t min_depth_for(uint32_t count) {
+        uint32_t d = 0;
+        uint64_t cap = MAX_LEAF_PRIMS;
+        while (cap < count) {
+            cap *= 2;
+            ++d;
+        }
+        return d;
+    }
+
+    // returns child ref, fills box
+    uint32_t build(uint32_t first, uint32_t count, uint32_t depth, Aabb *box_out) {
+        Aabb box = empty_box(), cbox = empty_box();
+        for (uint32_t i = first; i < first + count; ++i) {
+            uint32_t p = order[i];
+            grow(box, boxes[p]);
+            for (int k = 0; k < 3; ++k) {
+                double c = centroid(p, k);
+                cbox.mn[k] = std::fmin(cbox.mn[k], c);
+                cbox.mx[k] = std::fmax(cbox.mx[k], c);
+            }
+        }
+        *box_out = box;
+        if (depth > out.max_depth) out.max_depth = depth;
+
+        const uint32_t depth_budget = (STACK_DEPTH - 2) - depth;  // levels still available below this one
+        bool force_balanced = min_depth_for(count) + 1 >= depth_budget;
+        uint32_t mid = 0;
+        bool split_found = false;
+
+        if (count <= 2 || (count <= MAX_LEAF_PRIMS && depth_budget == 0)) {
+            out.n_leaves++;
+            return make_leaf_ref(first, count);
+        }
+
+        if (!force_balanced) {
+            double best_cost = std::numeric_limits<double>::infinity();
+            int best_axis = -1, best_bin = -1;
+            const double parent_area = area(box);
+            for (int axis = 0; axis < 3; ++axis) {
+                double lo = cbox.mn[axis], hi = cbox.mx[axis];
+                if (!(hi > lo)) continue;
+                double scale = kBins / (hi - lo);
+                uint32_t bin_count[kBins] = {0};
+                Aabb bin_box[kBins];
+                for (auto &b : bin_box) b = empty_box();
+                for (uint32_t i = first; i < first + count; ++i) {
+                    uint32_t p = order[i];
+                    int b = static_cast<int>((centroid(p, axis) - lo) * scale);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    bin_count[b]++;
+                    grow(bin_box[b], boxes[p]);
+                }
+                double right_area[kBins];
+                uint32_t right_count[kBins];
+                Aabb acc = empty_box();
+                uint32_t n = 0;
+                for (int b = kBins - 1; b >= 1; --b) {
+                    grow(acc, bin_box[b]);
+                    n += bin_count[b];
+                    right_area[b] = area(acc);
+                    right_count[b] = n;
+                }
+                acc = empty_box();
+                n = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    grow(acc, bin_box[b]);
+                    n += bin_count[b];
+                    if (n == 0 || right_count[b + 1] == 0) continue;
+                    double cost = area(acc) * n + right_area[b + 1] * right_count[b + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = axis;
+                        best_bin = b;
+                    }
+                }
+            }
+            if (best_axis >= 0) {
+                double split_cost = 1.0 + kIntersectCost * best_cost / (parent_area > 0.0 ? parent_area : 1.0);
+                double leaf_cost = kIntersectCost * count;
+                if (count <= kLeafTarget && leaf_cost <= split_cost) {
+                    out.n_leaves++;
+                    return make_leaf_ref(first, count);
+                }
+                double lo = cbox.mn[best_axis], hi = cbox.mx[best_axis];
+                double scale = kBins / (hi - lo);
+                auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t p) {
+                    int b = static_cast<int>((centroid(p, best_axis) - lo) * scale);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    return b <= best_bin;
+                });
+                mid = static_cast<uint32_t>(it - order.begin());
+                split_found = mid > first && mid < first + count;
+            } else if (count <= MAX_LEAF_PRIMS) {
+                out.n_leaves++;  // identical centroids: nothing to gain from splitting
+                return make_leaf_ref(first, count);
+            }
+        }
+        if (!split_found) {  // balanced median split (depth guard / degenerate centroids)
+            int axis = 0;
+            double ext = -1.0;
+            for (int k = 0; k < 3; ++k) {
+                double e = cbox.mx[k] - cbox.mn[k];
+                if (e > ext) {
+                    ext = e;
+                    axis = k;
+                }
+            }
+            mid = first + count / 2;
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) {
+                                 double ca = centroid(a, axis), cb = centroid(b, axis);
+                                 return ca < cb || (ca == cb && a < b);
+                             });
+        }
+
+        uint32_t self = static_cast<uint32_t>(out.nodes.size());
+        out.nodes.emplace_back();
+        Aabb lb, rb;
+        uint32_t l = build(first, mid - first, depth + 1, &lb);
+        uint32_t r = build(mid, first + count - mid, depth + 1, &rb);
+        BvhNode &n = out.nodes[self];
+        for (int k = 0; k < 3; ++k) {
+            n.lmin[k] = lb.mn[k];
+            n.lmax[k] = lb.mx[k];
+            n.rmin[k] = rb.mn[k];
+            n.rmax[k] = rb.mx[k];
+        }
+        n.left = l;
+        n.right = r;
+        for (uint32_t &p : n._pad) p = 0;
+        return self;
+    }
+};
+
+}  // namespace
+
+BvhBuildResult build_bvh(const std::vector<Aabb> &boxes) {
+    Builder b(boxes);
+    const uint32_t n = static_cast<uint32_t>(boxes.size());
+    if (n == 0) return std::move(b.out);
+    b.order.resize(n);
+    b.cx.resize(n);
+    b.cy.resize(n);
+    b.cz.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        b.order[i] = i;
+        b.cx[i] = 0.5 * (boxes[i].mn[0] + boxes[i].mx[0]);
+        b.cy[i] = 0.5 * (boxes[i].mn[1] + boxes[i].mx[1]);
+        b.cz[i] = 0.5 * (boxes[i].mn[2] + boxes[i].mx[2]);
+    }
+    b.out.nodes.reserve(n);
+    Aabb root;
+    b.out.root_ref = b.build(0, n, 0, &root);
+    b.out.root_box = root;
+    b.out.order = std::move(b.order);
+    return std::move(b.out);
+}
+
+}  // namespace rt

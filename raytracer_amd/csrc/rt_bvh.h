@@ -1,0 +1,32 @@
+// Host-side BVH build + linearisation (replaces KdTree::build,
+// src/core/bounds.rs:452-610, as the acceleration structure of the GPU path).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "rt_internal.h"
+
+namespace rt {
+
+struct Aabb {
+    double mn[3], mx[3];
+};
+
+struct BvhBuildResult {
+    std::vector<BvhNode> nodes;
+    std::vector<uint32_t> order;  // leaf-record order -> index into the input boxes
+    uint32_t root_ref = 0xFFFFFFFFu;
+    uint32_t max_depth = 0;
+    uint32_t n_leaves = 0;
+    Aabb root_box{};
+};
+
+// boxes: world AABBs of the bounded primitives.  Depth never exceeds
+// STACK_DEPTH - 1 so the per-lane LDS stack of the traversal kernels suffices.
+BvhBuildResult build_bvh(const std::vector<Aabb> &boxes);
+
+inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) {
+    return LEAF_FLAG | ((count - 1u) << 28) | first;
+}
+
+}  // namespace rt

@@ -1,0 +1,365 @@
+// rt_device_math.hip.h -- device-side f64 math of the hot path (gfx950).
+//
+// Everything that decides a hit (the primitives' own AABB slab test and the
+// four intersect routines) follows the reference's operation order exactly;
+// the translation unit is built with -ffp-contract=off so no multiply-add is
+// fused and every operation rounds like the reference's f64 code:
+//   src/core/bounds.rs:114-152          BoundingVolume::intersect
+//   src/primitives/sphere.rs:101-130    + src/utils/mod.rs:35-47 (quadratic)
+//   src/primitives/cube.rs:100-174
+//   src/primitives/plane.rs:98-117
+//   src/primitives/triangle.rs:193-232
+//   src/ray_intersection.rs:33-43,86-117  Ray::transform, compute_data
+// BVH node culling is NOT part of the hit predicate; it uses a cheaper,
+// provably conservative slab test (box_cull_*).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_internal.h"
+
+namespace rt {
+
+struct d3 {
+    double x, y, z;
+};
+
+__device__ __forceinline__ d3 mk3(double x, double y, double z) { return d3{x, y, z}; }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 operator-(d3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ d3 operator*(d3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ d3 operator*(double s, d3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ d3 operator/(d3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ d3 hadamard(d3 a, d3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ double dot3(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 cross3(d3 a, d3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double length3(d3 a) { return sqrt(dot3(a, a)); }
+__device__ __forceinline__ d3 unit3(d3 a) { return a / length3(a); }
+__device__ __forceinline__ d3 mix3(d3 a, d3 b, double t) { return a * (1.0 - t) + b * t; }  // nalgebra lerp
+__device__ __forceinline__ double comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// Rust f64::signum: +-1 by sign bit, NaN stays NaN
+__device__ __forceinline__ double rsign(double x) { return isnan(x) ? x : copysign(1.0, x); }
+// Rust f64::clamp(0,1): NaN stays NaN
+__device__ __forceinline__ double sat01(double c) { return c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c); }
+__device__ __forceinline__ d3 sat01(d3 a) { return {sat01(a.x), sat01(a.y), sat01(a.z)}; }
+__device__ __forceinline__ uint32_t cast_u32(double x) {  // Rust `as u32` (saturating, NaN -> 0)
+    if (!(x > 0.0)) return 0u;
+    if (x >= 4294967295.0) return 4294967295u;
+    return static_cast<uint32_t>(x);
+}
+__device__ __forceinline__ double lerp1(double x0, double x1, double t) { return x0 - x0 * t + x1 * t; }
+
+// Affine 3x4 row-major block in global memory
+__device__ __forceinline__ d3 xf_point(const double *__restrict__ m, d3 p) {
+    return {m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+            m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
+}
+__device__ __forceinline__ d3 xf_vector(const double *__restrict__ m, d3 v) {
+    return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+            m[8] * v.x + m[9] * v.y + m[10] * v.z};
+}
+__device__ __forceinline__ d3 xf_vector_t(const double *__restrict__ m, d3 v) {
+    return {m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z,
+            m[2] * v.x + m[6] * v.y + m[10] * v.z};
+}
+
+// ------------------------------------------------------------------ RNG
+// Philox4x32-10; stream layout in DESIGN.md "RNG".
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+__device__ __forceinline__ uint64_t path_child(uint64_t path, uint32_t slot) {
+    uint64_t z = path * 0xD1342543DE82EF95ull + (static_cast<uint64_t>(slot) + 1ull);
+    z ^= z >> 32;
+    z *= 0xD6E8FEB86659FD93ull;
+    z ^= z >> 32;
+    z *= 0xD6E8FEB86659FD93ull;
+    z ^= z >> 32;
+    return z;
+}
+
+__device__ __forceinline__ void rng_pair(uint64_t seed, uint32_t pixel, uint32_t sample, uint64_t path, double *u1,
+                                         double *u2) {
+    uint32_t r[4];
+    philox4x32_10(pixel, sample, static_cast<uint32_t>(path), static_cast<uint32_t>(path >> 32),
+                  static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32), r);
+    uint64_t a = static_cast<uint64_t>(r[0]) | (static_cast<uint64_t>(r[1]) << 32);
+    uint64_t b = static_cast<uint64_t>(r[2]) | (static_cast<uint64_t>(r[3]) << 32);
+    *u1 = static_cast<double>(a >> 11) * 0x1.0p-53;
+    *u2 = static_cast<double>(b >> 11) * 0x1.0p-53;
+}
+
+// ------------------------------------------------------------------ sampling (src/utils/sampling.rs)
+__device__ __forceinline__ d3 sample_cosine_hemisphere(d3 w, double u1, double u2) {
+    constexpr double HALF_PI = 1.57079632679489661923, QUARTER_PI = 0.78539816339744830962;
+    double rx = 2.0 * u1 - 1.0, ry = 2.0 * u2 - 1.0;
+    double px = 0.0, py = 0.0;
+    if (!(rx == 0.0 && ry == 0.0)) {
+        double r, theta;
+        if (fabs(rx) > fabs(ry)) {
+            r = rx;
+            theta = HALF_PI * (ry / rx);
+        } else {
+            r = ry;
+            theta = HALF_PI - QUARTER_PI * (rx / ry);
+        }
+        px = r * cos(theta);
+        py = r * sin(theta);
+    }
+    double pz = sqrt(1.0 - px * px - py * py);
+    d3 u = fabs(w.x) > F64_EPS ? cross3(w, mk3(0.0, 1.0, 0.0)) : cross3(w, mk3(1.0, 0.0, 0.0));
+    d3 v = cross3(w, u);
+    return unit3(u * px + v * py + w * pz);
+}
+
+__device__ __forceinline__ d3 sample_cone(d3 w, double max_angle, double u1, double u2) {
+    constexpr double HALF_PI = 1.57079632679489661923, TWO_PI = 6.28318530717958647692;
+    if (max_angle < F64_EPS) return w;
+    double theta = acos(u1);
+    theta = theta * max_angle / HALF_PI;
+    double z = cos(theta);
+    double radius = sin(theta);
+    double phi = u2 * TWO_PI;
+    d3 u = cross3(w, mk3(0.0, 0.0, 1.0));
+    double mag = length3(u);
+    if (mag < F64_EPS) return unit3(mk3(radius * cos(phi), radius * sin(phi), rsign(w.z) * z));
+    u = unit3(u);
+    d3 v = unit3(cross3(w, u));
+    return unit3(u * radius * cos(phi) + v * radius * sin(phi) + w * z);
+}
+
+// src/utils/rays.rs
+__device__ __forceinline__ d3 reflect_dir(d3 incident, d3 normal) {
+    return unit3(incident - (2.0 * dot3(incident, normal)) * normal);
+}
+__device__ __forceinline__ bool refract_dir(d3 incident, d3 normal, double eta, d3 *out) {
+    double n_dot_i = dot3(normal, incident);
+    d3 rn = n_dot_i < 0.0 ? normal : -normal;
+    eta = n_dot_i < 0.0 ? eta : 1.0 / eta;
+    n_dot_i = fabs(n_dot_i);
+    double k = 1.0 - eta * eta * (1.0 - n_dot_i * n_dot_i);
+    if (k < 0.0) return false;
+    *out = unit3(incident * eta - rn * (eta * n_dot_i - sqrt(k)));
+    return true;
+}
+
+// ------------------------------------------------------------------ hit predicates
+struct RayD {
+    d3 o, d;
+};
+
+// BoundingVolume::intersect (bounds.rs:114-152), reference operation order.
+__device__ __forceinline__ bool prim_box_test(const double *__restrict__ bmin, const double *__restrict__ bmax,
+                                              const RayD &r, bool has_max, double max_distance) {
+    double cx = (bmin[0] + bmax[0]) * 0.5, cy = (bmin[1] + bmax[1]) * 0.5, cz = (bmin[2] + bmax[2]) * 0.5;
+    double tcx = cx - r.o.x, tcy = cy - r.o.y, tcz = cz - r.o.z;
+    double hx = (bmax[0] - bmin[0]) / 2.0 * rsign(r.d.x);
+    double hy = (bmax[1] - bmin[1]) / 2.0 * rsign(r.d.y);
+    double hz = (bmax[2] - bmin[2]) / 2.0 * rsign(r.d.z);
+
+    double d_near = (tcx - hx) / r.d.x;
+    double d_far = (tcx + hx) / r.d.x;
+    double dy_near = (tcy - hy) / r.d.y;
+    double dy_far = (tcy + hy) / r.d.y;
+    if (dy_far < d_near || d_far < dy_near) return false;
+    d_near = dy_near > d_near ? dy_near : d_near;
+    d_far = d_far > dy_far ? dy_far : d_far;
+
+    double dz_near = (tcz - hz) / r.d.z;
+    double dz_far = (tcz + hz) / r.d.z;
+    if (dz_far < d_near || d_far < dz_near) return false;
+    d_near = dz_near > d_near ? dz_near : d_near;
+    d_far = d_far > dz_far ? dz_far : d_far;
+
+    if (d_near < 0.0 && d_far < 0.0) return false;
+    if (has_max && max_distance < d_near) return false;
+    return true;
+}
+
+struct HitRec {
+    double t;
+    double bu, bv;  // barycentrics (triangle) | bu = face code (cube: axis + 4*positive)
+};
+
+// side rule shared by sphere / cube: Both or shadow ray -> two-sided
+__device__ __forceinline__ bool is_two_sided(uint32_t side, bool shadow) { return side == RT_SIDE_BOTH || shadow; }
+
+__device__ __forceinline__ bool hit_sphere(double radius, uint32_t side, bool shadow, const RayD &r, bool has_max,
+                                           double max_distance, HitRec *h) {
+    double ray_proj = dot3(r.o, r.d);
+    double a = dot3(r.d, r.d);
+    double b = 2.0 * ray_proj;
+    double c = dot3(r.o, r.o) - radius * radius;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) return false;
+    double t0, t1;
+    if (disc == 0.0) {
+        t0 = -0.5 * b / a;
+        t1 = t0;
+    } else {
+        double q = -0.5 * (b + rsign(b) * sqrt(disc));
+        double r0 = q / a, r1 = c / q;
+        t0 = fmin(r0, r1);
+        t1 = fmax(r0, r1);
+    }
+    double dist;
+    if (is_two_sided(side, shadow)) dist = t0 < 0.0 ? t1 : t0;
+    else if (side == RT_SIDE_FRONT) dist = t0;
+    else dist = t1;
+    if (dist < 0.0 || (has_max && max_distance < dist)) return false;
+    h->t = dist;
+    h->bu = 0.0;
+    h->bv = 0.0;
+    return true;
+}
+
+__device__ __forceinline__ bool hit_cube(double size, uint32_t side, bool shadow, const RayD &r, bool has_max,
+                                         double max_distance, HitRec *h) {
+    double sx = rsign(r.d.x), sy = rsign(r.d.y), sz = rsign(r.d.z);
+    double half = size / 2.0;
+    int near_axis = 0, far_axis = 0;
+    bool near_pos = sx < 0.0, far_pos = sx > 0.0;
+    double d_near = (-r.o.x - sx * half) / r.d.x;
+    double d_far = (-r.o.x + sx * half) / r.d.x;
+    double dy_near = (-r.o.y - sy * half) / r.d.y;
+    double dy_far = (-r.o.y + sy * half) / r.d.y;
+    if (dy_far < d_near || d_far < dy_near) return false;
+    if (dy_near > d_near) {
+        near_axis = 1;
+        near_pos = sy < 0.0;
+        d_near = dy_near;
+    }
+    if (d_far > dy_far) {
+        far_axis = 1;
+        far_pos = sy > 0.0;
+        d_far = dy_far;
+    }
+    double dz_near = (-r.o.z - sz * half) / r.d.z;
+    double dz_far = (-r.o.z + sz * half) / r.d.z;
+    if (dz_far < d_near || d_far < dz_near) return false;
+    if (dz_near > d_near) {
+        near_axis = 2;
+        near_pos = sz < 0.0;
+        d_near = dz_near;
+    }
+    if (d_far > dz_far) {
+        far_axis = 2;
+        far_pos = sz > 0.0;
+        d_far = dz_far;
+    }
+    bool use_near = is_two_sided(side, shadow) ? !(d_near < 0.0) : (side == RT_SIDE_FRONT);
+    double dist = use_near ? d_near : d_far;
+    int axis = use_near ? near_axis : far_axis;
+    bool positive = use_near ? near_pos : far_pos;
+    if (dist < 0.0 || (has_max && max_distance < dist)) return false;
+    h->t = dist;
+    h->bu = static_cast<double>(axis + (positive ? 4 : 0));
+    h->bv = 0.0;
+    return true;
+}
+
+__device__ __forceinline__ bool hit_plane(d3 normal, uint32_t side, bool shadow, const RayD &r, bool has_max,
+                                          double max_distance, HitRec *h) {
+    double n_dot_v = dot3(normal, -r.d);
+    bool reject;
+    if (is_two_sided(side, shadow)) reject = fabs(n_dot_v) < F64_EPS;
+    else if (side == RT_SIDE_FRONT) reject = n_dot_v < F64_EPS;
+    else reject = -n_dot_v < F64_EPS;
+    if (reject) return false;
+    double dist = dot3(r.o, normal) / n_dot_v;
+    if (dist < 0.0 || (has_max && max_distance < dist)) return false;
+    h->t = dist;
+    h->bu = 0.0;
+    h->bv = 0.0;
+    return true;
+}
+
+__device__ __forceinline__ bool hit_triangle(const double *__restrict__ g, uint32_t side, bool shadow, const RayD &r,
+                                             bool has_max, double max_distance, HitRec *h) {
+    d3 p0 = mk3(g[0], g[1], g[2]);
+    d3 e1 = mk3(g[3], g[4], g[5]) - p0;
+    d3 e2 = mk3(g[6], g[7], g[8]) - p0;
+    d3 pv = cross3(r.d, e2);
+    double det = dot3(e1, pv);
+    bool reject;
+    if (is_two_sided(side, shadow)) reject = fabs(det) < F64_EPS;
+    else if (side == RT_SIDE_FRONT) reject = det < F64_EPS;
+    else reject = -det < F64_EPS;
+    if (reject) return false;
+    d3 tv = r.o - p0;
+    double u = dot3(tv, pv) / det;
+    if (!(u >= 0.0 && u <= 1.0)) return false;
+    d3 qv = cross3(tv, e1);
+    double v = dot3(r.d, qv) / det;
+    if (v < 0.0 || 1.0 < u + v) return false;
+    double dist = dot3(e2, qv) / det;
+    if (dist < 0.0 || (has_max && max_distance < dist)) return false;
+    h->t = dist;
+    h->bu = u;
+    h->bv = v;
+    return true;
+}
+
+// ------------------------------------------------------------------ BVH node culling
+// Conservative slab test: never rejects a box containing a primitive whose own
+// exact predicate passes.  Per ray: inv = 1/d, o_lo = o + P, o_hi = o - P with
+// P = 2^-47 * (|o|_inf + scene scale), i.e. 64 ulps of the coordinates (absorbs the rounding of this test AND of
+// the primitives' reference-order AABB arithmetic).  NaNs (0 * inf) drop out of
+// fmin/fmax, which keeps the slab -> conservative.
+struct CullRay {
+    d3 o_lo, o_hi, inv;
+};
+
+__device__ __forceinline__ CullRay make_cull_ray(const RayD &r, double scene_scale) {
+    double m = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
+    double P = 0x1.0p-47 * (m + scene_scale);
+    CullRay c;
+    c.o_lo = mk3(r.o.x + P, r.o.y + P, r.o.z + P);
+    c.o_hi = mk3(r.o.x - P, r.o.y - P, r.o.z - P);
+    c.inv = mk3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    return c;
+}
+
+// returns entry distance (lower bound) or +inf-like miss via `hit`
+__device__ __forceinline__ bool box_cull_test(const double *__restrict__ bmin, const double *__restrict__ bmax,
+                                              const CullRay &c, double t_limit, double *t_entry) {
+    double t1 = (bmin[0] - c.o_lo.x) * c.inv.x, t2 = (bmax[0] - c.o_hi.x) * c.inv.x;
+    double tn = fmin(t1, t2), tf = fmax(t1, t2);
+    t1 = (bmin[1] - c.o_lo.y) * c.inv.y;
+    t2 = (bmax[1] - c.o_hi.y) * c.inv.y;
+    tn = fmax(tn, fmin(t1, t2));
+    tf = fmin(tf, fmax(t1, t2));
+    t1 = (bmin[2] - c.o_lo.z) * c.inv.z;
+    t2 = (bmax[2] - c.o_hi.z) * c.inv.z;
+    tn = fmax(tn, fmin(t1, t2));
+    tf = fmin(tf, fmax(t1, t2));
+    *t_entry = tn;
+    // written so that any NaN keeps the node (comparisons false -> not culled)
+    if (tn > tf) return false;
+    if (tf < 0.0) return false;
+    if (tn > t_limit) return false;
+    return true;
+}
+
+}  // namespace rt

@@ -1,0 +1,172 @@
+// rt_internal.h -- device-resident data layout shared by host and kernels.
+//
+// Everything the wavefront kernels touch lives in HBM as flat arrays:
+//   * scene (read-only): BVH nodes (128 B, both children's boxes inline),
+//     leaf primitive records in BVH-leaf order (128 B: the primitive's own
+//     world AABB + object-space geometry), per-primitive shading records in
+//     primitive-ID order, transforms, materials, lights, textures;
+//   * wavefront state (per batch): SoA node pool (ray, hit/result, expansion
+//     info) and SoA shadow-ray pool, bump-allocated level by level.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/mi355rt.h"
+
+namespace rt {
+
+constexpr double BIAS = 1e-10;                   // src/render/mod.rs:14
+constexpr double GAMMA = 2.2;                    // src/render/mod.rs:13
+constexpr double F64_EPS = 2.220446049250313e-16;
+constexpr uint32_t MAX_LEVELS = 8;
+constexpr uint32_t STACK_DEPTH = 40;             // per-lane LDS traversal stack entries
+constexpr uint32_t MAX_LEAF_PRIMS = 8;
+constexpr uint32_t LEAF_FLAG = 0x80000000u;
+
+// RNG child slots (DESIGN.md "RNG"; identical constants in oracle/rt_oracle.cpp)
+constexpr uint32_t SLOT_REFRACTION = 0x40000000u;
+constexpr uint32_t SLOT_GI = 0x80000000u;
+
+// BVH2 node: boxes of both children, child references.
+// ref: bit31 set -> leaf, bits 28..30 = count-1, bits 0..27 = first leaf record.
+struct alignas(16) BvhNode {
+    double lmin[3], lmax[3];
+    double rmin[3], rmax[3];
+    uint32_t left, right;
+    uint32_t _pad[6];
+};
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
+
+// Leaf primitive record (bounded primitives only), BVH-leaf order.
+//   meta: bits 0..1 type, bits 2..3 side, bits 4..31 transform index
+//   geom: triangle p0 p1 p2 (object space) | geom[0] = sphere radius / cube size
+struct alignas(16) LeafPrim {
+    double bmin[3], bmax[3];  // the primitive's own world AABB (bounds.rs:40-72)
+    double geom[9];
+    uint32_t prim_id;
+    uint32_t meta;
+};
+static_assert(sizeof(LeafPrim) == 128, "LeafPrim must be 128 bytes");
+
+// Unbounded primitives (planes), scene order; tested for every ray.
+struct alignas(16) PlanePrim {
+    double normal[3];
+    uint32_t prim_id;
+    uint32_t meta;  // as LeafPrim::meta
+};
+
+// Shading-side record, primitive-ID order.
+struct alignas(16) ShadePrim {
+    uint32_t type;
+    uint32_t material;
+    uint32_t xf;
+    uint32_t tri;      // index into tri_nrm / tri_uv
+    double param;      // radius / size
+    double normal[3];  // plane normal
+    double uv_rot[6];  // plane: rows 0 and 2 of rotation_between(normal, +y)
+    uint32_t uv_ok;    // plane: rotation exists (reference panics otherwise)
+    uint32_t _pad;
+};
+
+struct DTexture {
+    uint32_t width, height;
+    uint64_t offset;  // byte offset into the texel buffer
+};
+
+struct DLight {
+    uint32_t kind, _pad;
+    double color[3];
+    double intensity;
+    double position[3];
+};
+
+struct SceneDev {
+    rt_render_options opts;
+    // camera
+    double cam_pos[3];
+    double cam_to_world[9];
+    double fov_scale;  // tan(fov/2), computed on the host
+    // acceleration structure
+    const BvhNode *nodes;
+    const LeafPrim *leaf_prims;
+    const PlanePrim *planes;
+    uint32_t root_ref;    // child-ref encoding; 0xFFFFFFFF = no bounded primitives
+    uint32_t n_planes;
+    uint32_t n_bounded;
+    uint32_t n_prims;
+    double scene_scale;   // max |coordinate| of the root box
+    // shading
+    const ShadePrim *shade_prims;
+    const double *inv_world;  // [n_transforms*12]
+    const double *tri_nrm;    // [n_tris*9]
+    const double *tri_uv;     // [n_tris*6]
+    const rt_material *materials;
+    const DLight *lights;
+    const DTexture *textures;
+    const uint8_t *texels;
+    uint32_t n_lights;
+    uint32_t n_point_lights;
+};
+
+// meta word of a node (ray) record
+//   bits 0..2  depth
+//   bit  3     kind: 0 = colour node (get_color), 1 = illumination node (get_illumination)
+//   bit  4     refraction child (ray carries the parent's material ior)
+//   bit  5     inactive (padding pixel outside the render window)
+//   bit  6     probe ray of rt_trace_rays (treated as Secondary)
+//   bits 8..31 material of the parent hit (valid when bit 4)
+constexpr uint32_t META_DEPTH_MASK = 7u;
+constexpr uint32_t META_ILLUM = 8u;
+constexpr uint32_t META_REFR = 16u;
+constexpr uint32_t META_INACTIVE = 32u;
+constexpr uint32_t META_MAT_SHIFT = 8u;
+
+// SoA node pool.  After resolve, (t,bu,bv) hold the node's RGB result and
+// `prim` its flag word (illumination nodes: 1 = occluded).
+struct NodePool {
+    double *ox, *oy, *oz;
+    double *dx, *dy, *dz;
+    uint64_t *path;
+    uint32_t *root;  // camera-ray index within the call's work list
+    uint32_t *meta;
+    // hit / result
+    uint32_t *prim;
+    double *t, *bu, *bv;
+    // expansion info
+    uint32_t *first_child;
+    uint32_t *first_shadow;
+    uint32_t *counts;      // nR | nT << 16 | nG << 17
+    uint32_t *light_mask;  // point lights that cast a shadow ray
+    uint32_t capacity;
+};
+
+struct ShadowPool {
+    double *dx, *dy, *dz;
+    double *tmax;
+    uint8_t *light;     // index among point lights
+    uint8_t *occluded;  // result
+    uint32_t capacity;
+};
+
+// Device-side counters of one batch.
+struct Counters {
+    uint32_t level_start[MAX_LEVELS + 1];
+    uint32_t level_count[MAX_LEVELS + 1];
+    unsigned long long node_alloc;    // bump pointer into the node pool
+    unsigned long long shadow_alloc;  // bump pointer into the shadow pool
+    uint32_t overflow;       // a pool ran out: the batch must be re-run smaller
+    uint32_t active_camera;  // camera rays inside the window
+    unsigned long long nodes_visited_closest, prims_tested_closest;
+    unsigned long long nodes_visited_shadow, prims_tested_shadow;
+};
+
+// One call's work list: tiles of tile_w x tile_h pixels, ns samples each.
+struct WorkList {
+    const uint32_t *tile_xy;  // [n_tiles*2] tile origin (pixels)
+    uint32_t n_tiles;
+    uint32_t tile_w, tile_h;
+    uint32_t x0, y0, x1, y1;  // window clip
+    uint32_t s0, ns;          // sample range [s0, s0+ns)
+    uint64_t seed;
+};
+
+}  // namespace rt

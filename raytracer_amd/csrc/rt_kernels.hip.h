@@ -1,0 +1,856 @@
+// rt_kernels.hip.h -- wavefront kernels of the hot path (gfx950, wave64).
+//
+// One batch of camera rays is expanded level by level into a node pool
+// (level d = rays of depth d).  Per level: closest-hit traversal -> expand
+// (emit child rays + shadow rays).  Then one any-hit launch over every shadow
+// ray of the batch, then a bottom-up resolve (the reference's ray tree is not a
+// linear throughput product: results are clamped at every get_color return and
+// the direct + GI term is scaled by the AO fraction, raytracing_scene.rs:246-258,
+// :465-486, :543), then a per-pixel accumulate.
+//
+//   reference function (raytracing_scene.rs)      kernel
+//   build_camera_rays :549-596                    k_raygen
+//   raycast :90 -> bounds.rs:302-364              k_trace_closest
+//   shadow_cast :94 -> bounds.rs:310-316,366-399  k_trace_shadow
+//   get_color / get_illumination :492-547,
+//     child-ray construction in :98-133,
+//     :135-167, :169-261, :263-337, :339-489      k_expand (rays) + k_resolve (radiance)
+//   screen_raycast :598-622 (sum over samples)    k_accumulate
+//   gamma + quantise :614-621, :757-769           k_tonemap
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_device_math.hip.h"
+#include "rt_internal.h"
+
+namespace rt {
+
+constexpr int BLOCK = 256;
+constexpr double PI_D = 3.14159265358979323846;
+constexpr double HALF_PI_D = 1.57079632679489661923;
+constexpr double INV_PI_D = 0.318309886183790671538;
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ void item_to_pixel(const WorkList &wl, uint32_t item, uint32_t *px, uint32_t *py,
+                                              uint32_t *sample) {
+    uint32_t s_local = item % wl.ns;
+    uint32_t pl = item / wl.ns;
+    uint32_t per_tile = wl.tile_w * wl.tile_h;
+    uint32_t tile = pl / per_tile, pit = pl % per_tile;
+    *px = wl.tile_xy[2 * tile] + pit % wl.tile_w;
+    *py = wl.tile_xy[2 * tile + 1] + pit / wl.tile_w;
+    *sample = wl.s0 + s_local;
+}
+
+// Wave-aggregated bump allocation: every lane of the wave must call it.
+__device__ __forceinline__ uint64_t wave_alloc(unsigned long long *counter, uint32_t n, uint32_t *wave_total) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t x = n;
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    uint32_t total = __shfl(x, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 63 && total) base = atomicAdd(counter, static_cast<unsigned long long>(total));
+    base = __shfl(base, 63, 64);
+    *wave_total = total;
+    return base + x - n;
+}
+
+__device__ __forceinline__ uint32_t ipow(uint32_t b, uint32_t e) {
+    uint32_t r = 1;
+    for (uint32_t i = 0; i < e; ++i) r *= b;
+    return r;
+}
+// raytracing_scene.rs:104-105 and :279-280 / :363-364
+__device__ __forceinline__ uint32_t gi_rays(const SceneDev &sc, uint32_t depth) {
+    uint32_t n = sc.opts.max_illumination_rays / ipow(4u, depth);
+    return n < 1u ? 1u : n;
+}
+__device__ __forceinline__ uint32_t refl_rays(const SceneDev &sc, uint32_t depth) {
+    uint32_t n = sc.opts.max_reflected_rays / ipow(8u, depth);
+    return n < 1u ? 1u : n;
+}
+
+struct Surface {
+    d3 P, n;      // world hit point, shading normal
+    d3 ohp, on;   // object-space hit point / normal (for uv)
+};
+
+// Intersection::compute_data (ray_intersection.rs:86-117) + surface_normal of each primitive
+__device__ __forceinline__ Surface compute_surface(const SceneDev &sc, const ShadePrim &sh, uint32_t side, d3 o, d3 d,
+                                                   double t, double bu, double bv) {
+    Surface s;
+    const double *inv = sc.inv_world + 12ull * sh.xf;
+    s.P = o + d * t;
+    s.ohp = xf_point(inv, s.P);
+    if (sh.type == RT_PRIM_SPHERE) {
+        s.on = unit3(s.ohp);
+    } else if (sh.type == RT_PRIM_CUBE) {  // cube.rs:188-210, face code = axis + 4*positive
+        const int code = static_cast<int>(bu);
+        const int axis = code & 3;
+        s.on = mk3(axis == 0 ? 1.0 : 0.0, axis == 1 ? 1.0 : 0.0, axis == 2 ? 1.0 : 0.0);
+        if (!(code & 4)) s.on = -s.on;
+    } else if (sh.type == RT_PRIM_PLANE) {
+        s.on = mk3(sh.normal[0], sh.normal[1], sh.normal[2]);
+    } else {
+        const double *n = sc.tri_nrm + 9ull * sh.tri;
+        double bw = 1.0 - bu - bv;
+        s.on = unit3(bw * mk3(n[0], n[1], n[2]) + bu * mk3(n[3], n[4], n[5]) + bv * mk3(n[6], n[7], n[8]));
+    }
+    d3 n = unit3(xf_vector_t(inv, s.on));
+    if (side == RT_SIDE_BOTH) {
+        if (dot3(n, d) > 0.0) n = -n;
+    } else if (side == RT_SIDE_BACK) {
+        n = -n;
+    }
+    s.n = n;
+    return s;
+}
+
+// uv of each primitive + Texture::get_color (texture.rs:46-69) + Material::get_color
+__device__ __forceinline__ d3 material_color(const SceneDev &sc, const ShadePrim &sh, const rt_material &m,
+                                             const Surface &s, double bu, double bv) {
+    d3 c = mk3(m.color[0], m.color[1], m.color[2]);
+    if (m.texture_id < 0) return c;
+    double u, v;
+    if (sh.type == RT_PRIM_SPHERE) {
+        d3 hp = s.ohp / sh.param;
+        u = atan2(hp.x, hp.z) * INV_PI_D * 0.5 + 0.5;
+        v = asin(hp.y) * INV_PI_D + 0.5;
+    } else if (sh.type == RT_PRIM_CUBE) {
+        d3 hp = mk3(s.ohp.x / sh.param + 0.5, s.ohp.y / sh.param + 0.5, s.ohp.z / sh.param + 0.5);
+        int code = static_cast<int>(bu);
+        int axis = code & 3;
+        if (code & 4) {
+            if (axis == 0) { u = -hp.z; v = hp.y; }
+            else if (axis == 1) { u = hp.x; v = -hp.z; }
+            else { u = hp.x; v = hp.y; }
+        } else {
+            if (axis == 0) { u = hp.z; v = hp.y; }
+            else if (axis == 1) { u = hp.x; v = hp.z; }
+            else { u = -hp.x; v = hp.y; }
+        }
+    } else if (sh.type == RT_PRIM_PLANE) {
+        if (sh.uv_ok) {
+            u = sh.uv_rot[0] * s.ohp.x + sh.uv_rot[1] * s.ohp.y + sh.uv_rot[2] * s.ohp.z;
+            v = sh.uv_rot[3] * s.ohp.x + sh.uv_rot[4] * s.ohp.y + sh.uv_rot[5] * s.ohp.z;
+        } else {
+            u = v = __builtin_nan("");
+        }
+    } else {
+        const double *t = sc.tri_uv + 6ull * sh.tri;
+        double bw = 1.0 - bu - bv;
+        u = bw * t[0] + bu * t[2] + bv * t[4];
+        v = bw * t[1] + bu * t[3] + bv * t[5];
+    }
+    const DTexture tx = sc.textures[m.texture_id];
+    uint32_t w = tx.width - 1u, h = tx.height - 1u;
+    double x = fmod(u, 1.0), y = fmod(v, 1.0);
+    x = x < 0.0 ? x + 1.0 : x;
+    y = y < 0.0 ? y + 1.0 : y;
+    x = x * static_cast<double>(w);
+    y = (1.0 - y) * static_cast<double>(h);
+    uint32_t xi = min(cast_u32(x), w), yi = min(cast_u32(y), h);
+    const uint8_t *px = sc.texels + tx.offset + (static_cast<uint64_t>(yi) * tx.width + xi) * 3ull;
+    d3 texel = mk3(static_cast<double>(px[0]) / 255.0, static_cast<double>(px[1]) / 255.0,
+                   static_cast<double>(px[2]) / 255.0);
+    return hadamard(c, texel);
+}
+
+// PointLight::get_color (lights/point.rs:32-34)
+__device__ __forceinline__ d3 light_radiance(const DLight &l, double dist) {
+    d3 c = mk3(l.intensity * l.color[0], l.intensity * l.color[1], l.intensity * l.color[2]) / (dist * dist);
+    return sat01(c);
+}
+
+// ------------------------------------------------------------------ batch bookkeeping
+__global__ void k_begin_batch(Counters *ctr, uint32_t n_items) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (uint32_t i = 0; i <= MAX_LEVELS; ++i) {
+            ctr->level_start[i] = 0;
+            ctr->level_count[i] = 0;
+        }
+        ctr->level_count[0] = n_items;
+        ctr->node_alloc = n_items;
+        ctr->shadow_alloc = 0;
+        ctr->overflow = 0;
+        ctr->active_camera = 0;
+        ctr->nodes_visited_closest = ctr->prims_tested_closest = 0;
+        ctr->nodes_visited_shadow = ctr->prims_tested_shadow = 0;
+    }
+}
+
+__global__ void k_advance_level(Counters *ctr, uint32_t level, uint32_t node_cap, uint32_t shadow_cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t start = ctr->level_start[level] + ctr->level_count[level];
+        if (ctr->node_alloc > node_cap || ctr->shadow_alloc > shadow_cap) ctr->overflow = 1;
+        ctr->level_start[level + 1] = start;
+        ctr->level_count[level + 1] = ctr->overflow ? 0u : static_cast<uint32_t>(ctr->node_alloc) - start;
+    }
+}
+
+// ------------------------------------------------------------------ ray generation
+__global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev sc, WorkList wl, NodePool np, Counters *ctr,
+                                                 uint32_t item0, uint32_t n_items) {
+    const double width = static_cast<double>(sc.opts.width), height = static_cast<double>(sc.opts.height);
+    const double aspect = width / height;
+    uint32_t n_active = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_items; i += gridDim.x * BLOCK) {
+        uint32_t item = item0 + i, px, py, sample;
+        item_to_pixel(wl, item, &px, &py, &sample);
+        bool active = px >= wl.x0 && px < wl.x1 && py >= wl.y0 && py < wl.y1;
+        np.root[i] = item;
+        np.path[i] = 0ull;
+        np.meta[i] = active ? 0u : META_INACTIVE;
+        if (!active) continue;
+        n_active++;
+        double fx, fy;
+        if (sample == 0) {  // raytracing_scene.rs:560
+            fx = static_cast<double>(px) + 0.5;
+            fy = static_cast<double>(py) + 0.5;
+        } else {            // :562-567, thread_rng replaced by the counter-based stream
+            double u1, u2;
+            rng_pair(wl.seed, py * sc.opts.width + px, sample, 0ull, &u1, &u2);
+            fx = static_cast<double>(px) + u1;
+            fy = static_cast<double>(py) + u2;
+        }
+        // remap_value (utils/mod.rs:29-33): (num - d0) * (r1 - r0) / (d1 - d0) + r0
+        double nx = (fx - 0.0) * (1.0 - -1.0) / (width - 0.0) + -1.0;
+        double ny = (fy - 0.0) * (-1.0 - 1.0) / (height - 0.0) + 1.0;
+        if (width < height) nx = nx * aspect;
+        else ny = ny / aspect;
+        nx = nx * sc.fov_scale;
+        ny = ny * sc.fov_scale;
+        d3 dir = unit3(mk3(nx, ny, -1.0));
+        const double *m = sc.cam_to_world;
+        d3 wd = mk3(m[0] * dir.x + m[1] * dir.y + m[2] * dir.z, m[3] * dir.x + m[4] * dir.y + m[5] * dir.z,
+                    m[6] * dir.x + m[7] * dir.y + m[8] * dir.z);
+        np.ox[i] = sc.cam_pos[0];
+        np.oy[i] = sc.cam_pos[1];
+        np.oz[i] = sc.cam_pos[2];
+        np.dx[i] = wd.x;
+        np.dy[i] = wd.y;
+        np.dz[i] = wd.z;
+    }
+    if (n_active) atomicAdd(&ctr->active_camera, n_active);
+}
+
+// ------------------------------------------------------------------ traversal
+struct ObjRayCache {
+    uint32_t xf;
+    RayD r;
+};
+
+template <bool SHADOW>
+__device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPrim *__restrict__ lp, const RayD &ray,
+                                               ObjRayCache &cache, bool has_max, double max_distance, HitRec *h) {
+    // BoundedObject::intersect (bounds.rs:172-181): own AABB first, then object space
+    if (!prim_box_test(lp->bmin, lp->bmax, ray, has_max, max_distance)) return false;
+    const uint32_t meta = lp->meta;
+    const uint32_t xf = meta >> 4;
+    if (xf != cache.xf) {  // Ray::transform (ray_intersection.rs:33-43), shared by a mesh's faces
+        const double *inv = sc.inv_world + 12ull * xf;
+        cache.r.o = xf_point(inv, ray.o);
+        cache.r.d = xf_vector(inv, ray.d);
+        cache.xf = xf;
+    }
+    const uint32_t type = meta & 3u, side = (meta >> 2) & 3u;
+    if (type == RT_PRIM_TRIANGLE) return hit_triangle(lp->geom, side, SHADOW, cache.r, has_max, max_distance, h);
+    if (type == RT_PRIM_SPHERE) return hit_sphere(lp->geom[0], side, SHADOW, cache.r, has_max, max_distance, h);
+    return hit_cube(lp->geom[0], side, SHADOW, cache.r, has_max, max_distance, h);
+}
+
+__device__ __forceinline__ double cull_limit(double t) { return t + 1e-9 * (1.0 + fabs(t)); }
+
+// KdTreeAccelerator::raycast semantics, traversal-order independent form
+// (DESIGN.md "canonical hit"): minimum of (t, bounded?, primitive id).
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, NodePool np, Counters *ctr, uint32_t level) {
+    __shared__ uint32_t stack[STACK_DEPTH * BLOCK];
+    if (ctr->overflow) return;
+    const uint32_t start = ctr->level_start[level], count = ctr->level_count[level];
+    unsigned long long n_nodes = 0, n_prims = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const uint32_t idx = start + i;
+        if (np.meta[idx] & META_INACTIVE) {
+            np.prim[idx] = RT_NO_HIT;
+            continue;
+        }
+        RayD ray;
+        ray.o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
+        ray.d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
+        double best_t = __builtin_inf();
+        uint32_t best_id = RT_NO_HIT;
+        double best_bu = 0.0, best_bv = 0.0;
+        bool best_bounded = false;
+
+        for (uint32_t p = 0; p < sc.n_planes; ++p) {  // unbounded objects first (bounds.rs:303-305)
+            const PlanePrim pl = sc.planes[p];
+            const double *inv = sc.inv_world + 12ull * (pl.meta >> 4);
+            RayD orr;
+            orr.o = xf_point(inv, ray.o);
+            orr.d = xf_vector(inv, ray.d);
+            HitRec h;
+            if (COUNT) n_prims++;
+            if (hit_plane(mk3(pl.normal[0], pl.normal[1], pl.normal[2]), (pl.meta >> 2) & 3u, false, orr, false, 0.0,
+                          &h) &&
+                (best_id == RT_NO_HIT || h.t < best_t)) {
+                best_t = h.t;
+                best_id = pl.prim_id;
+            }
+        }
+
+        if (sc.root_ref != 0xFFFFFFFFu) {
+            const CullRay cr = make_cull_ray(ray, sc.scene_scale);
+            ObjRayCache cache;
+            cache.xf = 0xFFFFFFFFu;
+            uint32_t sp = 0;
+            uint32_t cur = sc.root_ref;
+            while (true) {
+                if (cur & LEAF_FLAG) {
+                    const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
+                    for (uint32_t k = 0; k < n; ++k) {
+                        const LeafPrim *lp = sc.leaf_prims + first + k;
+                        HitRec h;
+                        if (COUNT) n_prims++;
+                        if (test_leaf_prim<false>(sc, lp, ray, cache, false, 0.0, &h)) {
+                            const uint32_t pid = lp->prim_id;
+                            bool better = best_id == RT_NO_HIT || h.t < best_t ||
+                                          (h.t == best_t && best_bounded && pid < best_id);
+                            if (better) {
+                                best_t = h.t;
+                                best_id = pid;
+                                best_bu = h.bu;
+                                best_bv = h.bv;
+                                best_bounded = true;
+                            }
+                        }
+                    }
+                    if (sp == 0) break;
+                    cur = stack[(--sp) * BLOCK + threadIdx.x];
+                } else {
+                    const BvhNode *nd = sc.nodes + cur;
+                    if (COUNT) n_nodes++;
+                    const double limit = cull_limit(best_t);
+                    double tl, tr;
+                    const bool hl = box_cull_test(nd->lmin, nd->lmax, cr, limit, &tl);
+                    const bool hr = box_cull_test(nd->rmin, nd->rmax, cr, limit, &tr);
+                    const uint32_t lref = nd->left, rref = nd->right;
+                    if (hl && hr) {
+                        const bool left_first = !(tr < tl);
+                        stack[(sp++) * BLOCK + threadIdx.x] = left_first ? rref : lref;
+                        cur = left_first ? lref : rref;
+                    } else if (hl) {
+                        cur = lref;
+                    } else if (hr) {
+                        cur = rref;
+                    } else {
+                        if (sp == 0) break;
+                        cur = stack[(--sp) * BLOCK + threadIdx.x];
+                    }
+                }
+            }
+        }
+        np.prim[idx] = best_id;
+        np.t[idx] = best_t;
+        np.bu[idx] = best_bu;
+        np.bv[idx] = best_bv;
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->nodes_visited_closest, n_nodes);
+        atomicAdd(&ctr->prims_tested_closest, n_prims);
+    }
+}
+
+// KdTreeAccelerator::shadow_cast semantics: OR over primitives within max_distance.
+// PROBE: rays come from the node pool (rt_trace_rays) instead of the shadow pool.
+template <bool COUNT, bool PROBE>
+__global__ __launch_bounds__(BLOCK) void k_trace_shadow(SceneDev sc, NodePool np, ShadowPool sp_pool, Counters *ctr,
+                                                       uint32_t probe_count) {
+    __shared__ uint32_t stack[STACK_DEPTH * BLOCK];
+    if (ctr->overflow) return;
+    const uint32_t count = PROBE ? probe_count : static_cast<uint32_t>(ctr->shadow_alloc);
+    unsigned long long n_nodes = 0, n_prims = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        RayD ray;
+        double tmax;
+        if (PROBE) {
+            ray.o = mk3(np.ox[i], np.oy[i], np.oz[i]);
+            ray.d = mk3(np.dx[i], np.dy[i], np.dz[i]);
+            tmax = np.t[i];
+        } else {
+            const DLight &l = sc.lights[sp_pool.light[i]];
+            ray.o = mk3(l.position[0], l.position[1], l.position[2]);
+            ray.d = mk3(sp_pool.dx[i], sp_pool.dy[i], sp_pool.dz[i]);
+            tmax = sp_pool.tmax[i];
+        }
+        bool occluded = false;
+        for (uint32_t p = 0; p < sc.n_planes && !occluded; ++p) {
+            const PlanePrim pl = sc.planes[p];
+            const double *inv = sc.inv_world + 12ull * (pl.meta >> 4);
+            RayD orr;
+            orr.o = xf_point(inv, ray.o);
+            orr.d = xf_vector(inv, ray.d);
+            HitRec h;
+            if (COUNT) n_prims++;
+            if (hit_plane(mk3(pl.normal[0], pl.normal[1], pl.normal[2]), (pl.meta >> 2) & 3u, true, orr, true, tmax,
+                          &h) &&
+                h.t <= tmax)
+                occluded = true;
+        }
+        if (!occluded && sc.root_ref != 0xFFFFFFFFu) {
+            const CullRay cr = make_cull_ray(ray, sc.scene_scale);
+            const double limit = cull_limit(tmax);
+            ObjRayCache cache;
+            cache.xf = 0xFFFFFFFFu;
+            uint32_t sp = 0;
+            uint32_t cur = sc.root_ref;
+            while (true) {
+                if (cur & LEAF_FLAG) {
+                    const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
+                    for (uint32_t k = 0; k < n && !occluded; ++k) {
+                        HitRec h;
+                        if (COUNT) n_prims++;
+                        if (test_leaf_prim<true>(sc, sc.leaf_prims + first + k, ray, cache, true, tmax, &h))
+                            occluded = true;
+                    }
+                    if (occluded || sp == 0) break;
+                    cur = stack[(--sp) * BLOCK + threadIdx.x];
+                } else {
+                    const BvhNode *nd = sc.nodes + cur;
+                    if (COUNT) n_nodes++;
+                    double tl, tr;
+                    const bool hl = box_cull_test(nd->lmin, nd->lmax, cr, limit, &tl);
+                    const bool hr = box_cull_test(nd->rmin, nd->rmax, cr, limit, &tr);
+                    const uint32_t lref = nd->left, rref = nd->right;
+                    if (hl && hr) {
+                        const bool left_first = !(tr < tl);
+                        stack[(sp++) * BLOCK + threadIdx.x] = left_first ? rref : lref;
+                        cur = left_first ? lref : rref;
+                    } else if (hl) {
+                        cur = lref;
+                    } else if (hr) {
+                        cur = rref;
+                    } else {
+                        if (sp == 0) break;
+                        cur = stack[(--sp) * BLOCK + threadIdx.x];
+                    }
+                }
+            }
+        }
+        if (PROBE) np.prim[i] = occluded ? 1u : 0u;
+        else sp_pool.occluded[i] = occluded ? 1 : 0;
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->nodes_visited_shadow, n_nodes);
+        atomicAdd(&ctr->prims_tested_shadow, n_prims);
+    }
+}
+
+// ------------------------------------------------------------------ expand
+// Emits the child rays and shadow rays of every node of `level`.
+// Child block layout of a node: [reflection x nR][refraction x nT][GI x nG].
+__global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, Counters *ctr,
+                                                 uint32_t level) {
+    if (ctr->overflow) return;
+    const uint32_t start = ctr->level_start[level], count = ctr->level_count[level];
+    const bool next_real = level + 1 < sc.opts.max_depth;
+    for (uint32_t base_i = blockIdx.x * BLOCK; base_i < count; base_i += gridDim.x * BLOCK) {
+        const uint32_t i = base_i + threadIdx.x;
+        const bool valid = i < count;
+        const uint32_t idx = start + (valid ? i : 0u);
+        uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0;
+        uint32_t prim = RT_NO_HIT, meta = 0;
+        d3 o{}, d{};
+        Surface s{};
+        ShadePrim sh{};
+        rt_material m{};
+        d3 refr_dir{};
+        bool illum = false;
+        if (valid) {
+            meta = np.meta[idx];
+            prim = (meta & META_INACTIVE) ? RT_NO_HIT : np.prim[idx];
+        }
+        if (prim != RT_NO_HIT) {
+            illum = (meta & META_ILLUM) != 0;
+            o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
+            d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
+            sh = sc.shade_prims[prim];
+            m = sc.materials[sh.material];
+            s = compute_surface(sc, sh, m.side, o, d, np.t[idx], np.bu[idx], np.bv[idx]);
+            bool cast_shadows = false;
+            if (m.kind == RT_MAT_PHONG) {
+                nR = m.reflectivity > 0.0 ? 1u : 0u;
+                if (!illum) {
+                    nG = gi_rays(sc, level);
+                    cast_shadows = m.reflectivity < 1.0;
+                }
+            } else {
+                nR = sc.opts.max_reflected_rays > 0 ? refl_rays(sc, level) : 0u;
+                if (m.opacity < 1.0) {
+                    double ray_ior = (meta & META_REFR) ? sc.materials[meta >> META_MAT_SHIFT].refractive_index : 1.0;
+                    double eta = ray_ior / m.refractive_index;
+                    if (refract_dir(d, s.n, eta, &refr_dir)) nT = 1;
+                }
+                if (!illum) {
+                    nG = gi_rays(sc, level);
+                    cast_shadows = true;
+                }
+            }
+            if (!next_real) nR = nT = nG = 0;
+            if (cast_shadows) {
+                uint32_t bit = 0;
+                for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                    const DLight &l = sc.lights[li];
+                    if (l.kind != RT_LIGHT_POINT) continue;
+                    d3 ld = mk3(l.position[0], l.position[1], l.position[2]) - s.P;
+                    ld = unit3(ld);
+                    if (dot3(s.n, ld) > 0.0) {
+                        mask |= 1u << bit;
+                        nS++;
+                    }
+                    bit++;
+                }
+            }
+        }
+        const uint32_t total = nR + nT + nG;
+        uint32_t wave_nodes, wave_shadows;
+        const uint64_t child64 = wave_alloc(&ctr->node_alloc, total, &wave_nodes);
+        const uint64_t shadow64 = wave_alloc(&ctr->shadow_alloc, nS, &wave_shadows);
+        // wave-uniform overflow test (first lane's base + wave total)
+        const uint64_t node_base = __shfl(child64, 0, 64), shadow_base = __shfl(shadow64, 0, 64);
+        const uint32_t first_child = static_cast<uint32_t>(child64), first_shadow = static_cast<uint32_t>(shadow64);
+        if (node_base + wave_nodes > np.capacity || shadow_base + wave_shadows > sp.capacity) {
+            if ((threadIdx.x & 63u) == 0) atomicOr(&ctr->overflow, 1u);
+            continue;
+        }
+        if (!valid) continue;
+        np.first_child[idx] = first_child;
+        np.first_shadow[idx] = first_shadow;
+        np.counts[idx] = nR | (nT << 16) | (nG << 17);
+        np.light_mask[idx] = mask;
+        if (prim == RT_NO_HIT) continue;
+
+        // shadow rays: from the light towards the surface (raytracing_scene.rs:217-225, :429-437)
+        if (nS) {
+            uint32_t bit = 0, k = first_shadow;
+            for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                const DLight &l = sc.lights[li];
+                if (l.kind != RT_LIGHT_POINT) continue;
+                if (mask & (1u << bit)) {
+                    d3 ld = mk3(l.position[0], l.position[1], l.position[2]) - s.P;
+                    double dist = length3(ld);
+                    ld = unit3(ld);
+                    sp.dx[k] = -ld.x;
+                    sp.dy[k] = -ld.y;
+                    sp.dz[k] = -ld.z;
+                    sp.tmax[k] = dist - BIAS;  // shadow_cast(.., max_distance - BIAS), :94-96
+                    sp.light[k] = static_cast<uint8_t>(li);
+                    k++;
+                }
+                bit++;
+            }
+        }
+        if (total == 0) continue;
+
+        const uint32_t root = np.root[idx];
+        const uint64_t path = np.path[idx];
+        uint32_t px, py, sample;
+        item_to_pixel(wl, root, &px, &py, &sample);
+        const uint32_t pixel = py * sc.opts.width + px;
+        const uint32_t child_depth = level + 1;
+        uint32_t c = first_child;
+        auto emit = [&](uint32_t at, d3 dir, uint64_t cpath, uint32_t cmeta) {
+            d3 org = s.P + dir * BIAS;
+            np.ox[at] = org.x;
+            np.oy[at] = org.y;
+            np.oz[at] = org.z;
+            np.dx[at] = dir.x;
+            np.dy[at] = dir.y;
+            np.dz[at] = dir.z;
+            np.path[at] = cpath;
+            np.root[at] = root;
+            np.meta[at] = cmeta;
+        };
+        const uint32_t same_kind = child_depth | (illum ? META_ILLUM : 0u);
+        if (nR) {
+            d3 rdir = reflect_dir(d, s.n);
+            if (m.kind == RT_MAT_PHONG) {
+                emit(c++, rdir, path_child(path, 0u), same_kind);
+            } else {
+                const double max_angle = HALF_PI_D * m.roughness;
+                for (uint32_t r = 0; r < nR; ++r) {
+                    uint64_t cp = path_child(path, r);
+                    double u1, u2;
+                    rng_pair(wl.seed, pixel, sample, cp, &u1, &u2);
+                    emit(c++, sample_cone(rdir, max_angle, u1, u2), cp, same_kind);
+                }
+            }
+        }
+        if (nT) emit(c++, refr_dir, path_child(path, SLOT_REFRACTION), same_kind | META_REFR | (sh.material << META_MAT_SHIFT));
+        for (uint32_t g = 0; g < nG; ++g) {
+            uint64_t cp = path_child(path, SLOT_GI + g);
+            double u1, u2;
+            rng_pair(wl.seed, pixel, sample, cp, &u1, &u2);
+            emit(c++, sample_cosine_hemisphere(s.n, u1, u2), cp, child_depth | META_ILLUM);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ resolve
+// Bottom-up shading of every node of `level`; children of level+1 are resolved.
+// Result: (t,bu,bv) <- RGB, prim <- flag (illumination nodes: occluded).
+__global__ __launch_bounds__(BLOCK) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctr,
+                                                  uint32_t level) {
+    if (ctr->overflow) return;
+    const uint32_t start = ctr->level_start[level], count = ctr->level_count[level];
+    const bool next_real = level + 1 < sc.opts.max_depth;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const uint32_t idx = start + i;
+        const uint32_t meta = np.meta[idx];
+        const uint32_t prim = (meta & META_INACTIVE) ? RT_NO_HIT : np.prim[idx];
+        d3 result = mk3(0.0, 0.0, 0.0);
+        uint32_t flag = 0;
+        if (prim != RT_NO_HIT) {
+            const bool illum = (meta & META_ILLUM) != 0;
+            const d3 o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
+            const d3 d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
+            const double t = np.t[idx], bu = np.bu[idx], bv = np.bv[idx];
+            const ShadePrim sh = sc.shade_prims[prim];
+            const rt_material m = sc.materials[sh.material];
+            const Surface s = compute_surface(sc, sh, m.side, o, d, t, bu, bv);
+            const d3 mc = material_color(sc, sh, m, s, bu, bv);
+            const d3 emissive = mk3(m.emissive[0], m.emissive[1], m.emissive[2]);
+            const uint32_t counts = np.counts[idx];
+            const uint32_t nT = (counts >> 16) & 1u;
+            uint32_t child = np.first_child[idx];
+            auto child_rgb = [&](uint32_t at) { return mk3(np.t[at], np.bu[at], np.bv[at]); };
+
+            if (illum) {
+                // get_emissive_phong :135-167 / get_emissive_physical :263-337
+                if (m.kind == RT_MAT_PHONG) {
+                    result = emissive;
+                    if (m.reflectivity > 0.0) {
+                        d3 incoming = next_real ? child_rgb(child) : mk3(0.0, 0.0, 0.0);
+                        result = result + hadamard(incoming, mc) * m.reflectivity;
+                    }
+                } else {
+                    result = emissive;
+                    if (sc.opts.max_reflected_rays > 0) {
+                        const uint32_t n = refl_rays(sc, level);
+                        d3 acc = mk3(0.0, 0.0, 0.0);
+                        for (uint32_t r = 0; r < n; ++r)
+                            acc = acc + (next_real ? child_rgb(child + r) : mk3(0.0, 0.0, 0.0));
+                        if (next_real) child += n;
+                        acc = acc * (HALF_PI_D / static_cast<double>(n));
+                        result = result + hadamard(acc, mc);
+                    }
+                    bool has_refr;
+                    if (next_real) {
+                        has_refr = nT != 0;
+                    } else {  // child not materialised: redo the TIR test of :307-309
+                        has_refr = false;
+                        if (m.opacity < 1.0) {
+                            double ray_ior =
+                                (meta & META_REFR) ? sc.materials[meta >> META_MAT_SHIFT].refractive_index : 1.0;
+                            d3 dummy;
+                            has_refr = refract_dir(d, s.n, ray_ior / m.refractive_index, &dummy);
+                        }
+                    }
+                    if (has_refr) {
+                        d3 pass = next_real ? child_rgb(child) : mk3(0.0, 0.0, 0.0);
+                        result = result + pass * (1.0 - m.opacity);
+                    }
+                }
+                flag = t <= sc.opts.max_occlusion_distance ? 1u : 0u;  // :512-516
+            } else {
+                // ---- children: reflection / refraction
+                bool has_refl = false, has_refr = false;
+                d3 reflection = mk3(0.0, 0.0, 0.0), refraction = mk3(0.0, 0.0, 0.0);
+                d3 f = mk3(0.0, 0.0, 0.0), diffuse = mk3(0.0, 0.0, 0.0);
+                double n_dot_v = 0.0, roughness = 0.0;
+                if (m.kind == RT_MAT_PHONG) {
+                    if (m.reflectivity > 0.0) {  // :184-199
+                        has_refl = true;
+                        d3 cc = next_real ? child_rgb(child) : mk3(0.0, 0.0, 0.0);
+                        if (next_real) child += 1;
+                        reflection = hadamard(cc, mc);
+                    }
+                } else {  // :350-411
+                    d3 view_dir = unit3(-d);
+                    n_dot_v = fmax(dot3(s.n, view_dir), 0.0);
+                    roughness = fmax(m.roughness, 0.04);
+                    d3 base = mix3(mk3(0.04, 0.04, 0.04), mc, m.metalness);
+                    f = base + (mk3(1.0, 1.0, 1.0) - base) * pow(1.0 - n_dot_v, 5.0);
+                    d3 k_d = (mk3(1.0, 1.0, 1.0) - f) * (1.0 - m.metalness);
+                    diffuse = INV_PI_D * hadamard(k_d, mc);
+                    if (sc.opts.max_reflected_rays > 0) {
+                        has_refl = true;
+                        const uint32_t n = refl_rays(sc, level);
+                        for (uint32_t r = 0; r < n; ++r)
+                            reflection = reflection + (next_real ? sat01(child_rgb(child + r)) : mk3(0.0, 0.0, 0.0));
+                        if (next_real) child += n;
+                        reflection = reflection * (HALF_PI_D / static_cast<double>(n));
+                    }
+                    if (next_real) {
+                        has_refr = nT != 0;
+                    } else if (m.opacity < 1.0) {
+                        double ray_ior =
+                            (meta & META_REFR) ? sc.materials[meta >> META_MAT_SHIFT].refractive_index : 1.0;
+                        d3 dummy;
+                        has_refr = refract_dir(d, s.n, ray_ior / m.refractive_index, &dummy);
+                    }
+                    if (has_refr) {
+                        d3 cc = next_real ? child_rgb(child) : mk3(0.0, 0.0, 0.0);
+                        if (next_real) child += 1;
+                        refraction = hadamard(cc, mix3(mk3(1.0, 1.0, 1.0), f, m.opacity));
+                    }
+                }
+                // ---- direct lighting
+                d3 ambient = mk3(0.0, 0.0, 0.0), irradiance = mk3(0.0, 0.0, 0.0);
+                if (m.kind == RT_MAT_PHYSICAL || m.reflectivity < 1.0) {
+                    const uint32_t mask = np.light_mask[idx];
+                    uint32_t bit = 0, k = np.first_shadow[idx];
+                    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+                        const DLight &l = sc.lights[li];
+                        if (l.kind == RT_LIGHT_AMBIENT) {
+                            ambient = ambient + hadamard(mk3(l.color[0], l.color[1], l.color[2]), mc);
+                            continue;
+                        }
+                        const bool lit_side = (mask >> bit) & 1u;
+                        bit++;
+                        if (!lit_side) continue;  // n.l <= 0 (decided in k_expand with the same arithmetic)
+                        const bool occluded = sp.occluded[k++] != 0;
+                        if (occluded) continue;
+                        d3 ld = mk3(l.position[0], l.position[1], l.position[2]) - s.P;
+                        const double dist = length3(ld);
+                        ld = unit3(ld);
+                        const double n_dot_l = dot3(s.n, ld);
+                        const d3 lc = light_radiance(l, dist);
+                        const d3 half_vec = unit3(ld - d);
+                        if (m.kind == RT_MAT_PHONG) {  // :226-235
+                            irradiance = irradiance + hadamard(lc, mc) * n_dot_l;
+                            const double n_dot_h = dot3(s.n, half_vec);
+                            if (n_dot_h > 0.0)
+                                irradiance = irradiance + hadamard(lc, mk3(m.specular[0], m.specular[1], m.specular[2])) *
+                                                              pow(n_dot_h, m.shininess);
+                        } else {  // :438-454
+                            const double n_dot_h = fmax(dot3(s.n, half_vec), 0.0);
+                            const d3 radiance = lc * n_dot_l;
+                            // ndf / geometry_function (utils/physical_material_equations.rs)
+                            const double a = roughness * roughness, a2 = a * a;
+                            double denom = n_dot_h * n_dot_h * (a2 - 1.0) + 1.0;
+                            denom = PI_D * denom * denom;
+                            const double ndf = a2 / denom;
+                            const double rr = roughness + 1.0, kk = rr * rr / 8.0;
+                            const double g = (n_dot_v / (n_dot_v * (1.0 - kk) + kk)) * (n_dot_l / (n_dot_l * (1.0 - kk) + kk));
+                            d3 ds = diffuse;
+                            if (!(n_dot_v == 0.0)) ds = diffuse + ((ndf * g) * f) / (4.0 * n_dot_v * n_dot_l);
+                            irradiance = irradiance + hadamard(ds, radiance) * n_dot_l;
+                        }
+                    }
+                }
+                // ---- global illumination / ambient occlusion, :98-133
+                const uint32_t nG = gi_rays(sc, level);
+                d3 incoming = mk3(0.0, 0.0, 0.0);
+                uint32_t unoccluded = nG;
+                if (next_real) {
+                    unoccluded = 0;
+                    for (uint32_t g = 0; g < nG; ++g) {
+                        incoming = incoming + child_rgb(child + g);
+                        if (np.prim[child + g] == 0u) unoccluded++;
+                    }
+                }
+                incoming = incoming / static_cast<double>(nG);
+                const double ao = static_cast<double>(unoccluded) / static_cast<double>(nG);
+                const d3 gi_tint = m.kind == RT_MAT_PHONG ? mc : diffuse;
+                d3 color = emissive + (ambient + irradiance + hadamard(incoming, gi_tint)) * ao;
+                if (has_refl) {
+                    if (m.kind == RT_MAT_PHONG) color = mix3(color, sat01(reflection), m.reflectivity);  // :254-258
+                    else color = mk3(lerp1(color.x, reflection.x, f.x), lerp1(color.y, reflection.y, f.y),
+                                     lerp1(color.z, reflection.z, f.z));                              // :473-479
+                }
+                if (has_refr) color = mix3(sat01(refraction), color, m.opacity);                      // :481-486
+                result = sat01(color);                                                                  // :543
+            }
+        }
+        np.t[idx] = result.x;
+        np.bu[idx] = result.y;
+        np.bv[idx] = result.z;
+        np.prim[idx] = flag;
+    }
+}
+
+// ------------------------------------------------------------------ accumulate / tonemap / AOVs
+// screen_raycast :605-612: sum of the per-sample clamped colours, in sample order.
+__global__ __launch_bounds__(BLOCK) void k_accumulate(SceneDev sc, WorkList wl, NodePool np, Counters *ctr,
+                                                     uint32_t item0, uint32_t n_items, double *accum) {
+    if (ctr->overflow) return;
+    const uint32_t n_pix = n_items / wl.ns;
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < n_pix; p += gridDim.x * BLOCK) {
+        const uint32_t node0 = p * wl.ns;
+        if (np.meta[node0] & META_INACTIVE) continue;
+        uint32_t px, py, sample;
+        item_to_pixel(wl, item0 + node0, &px, &py, &sample);
+        d3 sum = mk3(np.t[node0], np.bu[node0], np.bv[node0]);
+        for (uint32_t s = 1; s < wl.ns; ++s) sum = sum + mk3(np.t[node0 + s], np.bu[node0 + s], np.bv[node0 + s]);
+        const uint64_t at = (static_cast<uint64_t>(py) * sc.opts.width + px) * 3ull;
+        accum[at] += sum.x;
+        accum[at + 1] += sum.y;
+        accum[at + 2] += sum.z;
+    }
+}
+
+// :614-621 + :757-769
+__global__ __launch_bounds__(BLOCK) void k_tonemap(uint32_t n_pixels, uint32_t spp, const double *accum,
+                                                  uint8_t *rgba) {
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < n_pixels; p += gridDim.x * BLOCK) {
+        d3 c = mk3(accum[3ull * p], accum[3ull * p + 1], accum[3ull * p + 2]);
+        if (spp != 1) c = sat01(c * (1.0 / static_cast<double>(spp)));
+        c = sat01(c);
+        const double e = 1.0 / GAMMA;
+        c = mk3(pow(c.x, e), pow(c.y, e), pow(c.z, e));
+        auto q = [](double v) -> uint8_t {  // `(c * 255.0) as u8`
+            double x = v * 255.0;
+            if (!(x > 0.0)) return 0;
+            if (x >= 255.0) return 255;
+            return static_cast<uint8_t>(x);
+        };
+        rgba[4ull * p] = q(c.x);
+        rgba[4ull * p + 1] = q(c.y);
+        rgba[4ull * p + 2] = q(c.z);
+        rgba[4ull * p + 3] = 255;
+    }
+}
+
+// primary-hit AOVs of level-0 nodes (one sample per pixel): id, t, shading normal
+__global__ __launch_bounds__(BLOCK) void k_primary_aov(SceneDev sc, WorkList wl, NodePool np, uint32_t item0,
+                                                      uint32_t n_items, uint32_t *out_id, double *out_t,
+                                                      double *out_n) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_items; i += gridDim.x * BLOCK) {
+        if (np.meta[i] & META_INACTIVE) continue;
+        uint32_t px, py, sample;
+        item_to_pixel(wl, item0 + i, &px, &py, &sample);
+        const uint64_t at = static_cast<uint64_t>(py) * sc.opts.width + px;
+        const uint32_t prim = np.prim[i];
+        out_id[at] = prim;
+        if (prim == RT_NO_HIT) {
+            out_t[at] = 0.0;
+            out_n[3 * at] = out_n[3 * at + 1] = out_n[3 * at + 2] = 0.0;
+            continue;
+        }
+        const ShadePrim sh = sc.shade_prims[prim];
+        const rt_material m = sc.materials[sh.material];
+        const d3 o = mk3(np.ox[i], np.oy[i], np.oz[i]), d = mk3(np.dx[i], np.dy[i], np.dz[i]);
+        const Surface s = compute_surface(sc, sh, m.side, o, d, np.t[i], np.bu[i], np.bv[i]);
+        out_t[at] = np.t[i];
+        out_n[3 * at] = s.n.x;
+        out_n[3 * at + 1] = s.n.y;
+        out_n[3 * at + 2] = s.n.z;
+    }
+}
+
+}  // namespace rt
