@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the MI355X hot path on BASELINE.json's headline config.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is ONE frame of scenes/scene.json (800x800, 4 spp, 1,524 primitives,
+~147 M rays; BASELINE configs[2]): the scene is resident in HBM, every rank
+renders its Morton-interleaved tile shard into a zeroed f64 accumulation buffer
+through the C ABI (rt_render_device), one RCCL reduce(SUM) assembles the frame
+on rank 0, rank 0 tonemaps to RGBA8 on the device.  Total work is fixed as N
+grows ("strong" scaling).  value = rays of all ranks / max-over-ranks time.
+
+Rank 0 prints one JSON line; with N = 1 it also carries
+  roofline     -- the dominant kernel class (HIP-event time inside the library,
+                  on the stream the kernels run on) against the HBM peak, using
+                  SURVEY.md 8(d)'s algorithmic bytes per ray;
+  cpu_baseline -- the oracle's reference-order kd-tree renderer (a C++ port of
+                  the Rust reference, which cannot be built here) on the host
+                  cores, on a bounded sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+PUBLISHED = {}         # BASELINE.json "published": {} -> vs_baseline is null
+
+
+def algorithmic_bytes(kind, nodes_per_ray, tri_per_ray, analytic_per_ray):
+    """closest-hit ray 224 B, shadow ray 136 B of wavefront
+    records + 64 B per BVH2 node visited + 72 B per triangle / 104 B per
+    analytic primitive tested."""
+    base = 224.0 if kind == "closest" else 136.0
+    return base + 64.0 * nodes_per_ray + 72.0 * tri_per_ray + 104.0 * analytic_per_ray
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "scene.json"))
+    ap.add_argument("--spp", type=int, default=0, help="override samples_per_pixel (0 = scene file)")
+    ap.add_argument("--size", type=int, default=0, help="override width=height (0 = scene file)")
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--sample-shards", type=int, default=1)
+    ap.add_argument("--pool-gib", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from raytracer_amd import _abi, device, distributed, host
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene = host.LoadedScene.from_file(args.scene)
+    if args.spp:
+        scene.set_option("samples_per_pixel", args.spp)
+    if args.size:
+        scene.set_option("width", args.size)
+        scene.set_option("height", args.size)
+    w, h, spp = int(scene.opts.width), int(scene.opts.height), int(scene.opts.samples_per_pixel)
+    gpu = device.DeviceScene(scene.desc, pool_bytes=int(args.pool_gib * (1 << 30)) or None)
+    accum = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    stats_log = []
+
+    def render_local(params, acc, flags=0):
+        params.flags = flags
+        n, st = gpu.render_device(acc.data_ptr(), params, stream=stream, want_stats=True)
+        stats_log.append(st)
+        return n
+
+    def step(flags=0):
+        accum.zero_()
+        total, _ = distributed.render_frame(lambda p, a: render_local(p, a, flags), accum, rank, world, spp, seed=0,
+                                            tile_size=args.tile, sample_shards=args.sample_shards, dist=dist)
+        if rank == 0:
+            gpu.tonemap_device(accum.data_ptr(), rgba.data_ptr(), stream=stream)
+        return total
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    stats_log.clear()
+    fence()
+    t0 = time.perf_counter()
+    rays = 0
+    for _ in range(args.steps):
+        rays += step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    timed_stats = list(stats_log)
+    out = None
+    if rank == 0:
+        value = rays / elapsed / 1e6
+        out = {
+            "metric": "Mrays/sec (whole node) on scene.json 800x800 4spp", "value": round(value, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{os.path.basename(args.scene)} {w}x{h} {spp}spp, {scene.n_prims} primitives, "
+                            f"{rays // max(1, args.steps)} rays/frame (BASELINE configs[2]); scene resident in HBM, frame reduced to rank 0",
+                "parallelism": f"tiles{world}" + (f"xsamples{args.sample_shards}" if args.sample_shards > 1 else ""),
+                "tile": args.tile, "rays_per_step": rays // max(1, args.steps),
+            },
+        }
+
+    if world == 1 and rank == 0:
+        # ---- roofline of the dominant kernel class (one extra untimed frame counts BVH work)
+        stats_log.clear()
+        step(_abi.RT_FLAG_COUNT_WORK)
+        torch.cuda.synchronize()
+        work = stats_log[-1]
+        prim_types = scene.prim_types()
+        tri_share = float((prim_types == _abi.RT_PRIM_TRIANGLE).mean()) if len(prim_types) else 0.0
+        n_steps = max(1, len(timed_stats))
+        ms = {k: sum(getattr(s, "ms_" + k) for s in timed_stats) / n_steps for k in ("raygen", "closest", "shadow", "expand", "resolve", "accum")}
+        launches = {"closest": sum(s.launches_closest for s in timed_stats) / n_steps, "shadow": sum(s.launches_shadow for s in timed_stats) / n_steps}
+        nodes_c = work.nodes_visited_closest / max(1, work.closest_rays)
+        prims_c = work.prims_tested_closest / max(1, work.closest_rays)
+        nodes_s = work.nodes_visited_shadow / max(1, work.shadow_rays)
+        prims_s = work.prims_tested_shadow / max(1, work.shadow_rays)
+        bytes_c = algorithmic_bytes("closest", nodes_c, prims_c * tri_share, prims_c * (1 - tri_share))
+        bytes_s = algorithmic_bytes("shadow", nodes_s, prims_s * tri_share, prims_s * (1 - tri_share))
+        dominant = max(ms, key=ms.get)
+        kern = "closest" if dominant not in ("closest", "shadow") else dominant
+        k_rays = work.closest_rays if kern == "closest" else work.shadow_rays
+        k_bytes = bytes_c if kern == "closest" else bytes_s
+        k_ms = ms[kern]
+        achieved = k_rays * k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("k_trace_" + kern, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_trace_" + kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "launches_per_step": launches[kern], "avg_launch_ms": round(k_ms / max(1.0, launches[kern]), 4),
+            "algorithmic_bytes_per_ray": round(k_bytes, 1), "rays_per_step": int(k_rays),
+            "nodes_per_ray": round(nodes_c if kern == "closest" else nodes_s, 2),
+            "prims_per_ray": round(prims_c if kern == "closest" else prims_s, 2),
+            "kernel_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
+            "dominant_class": dominant,
+            "pipeline_gbs": round((work.closest_rays * bytes_c + work.shadow_rays * bytes_s) / (elapsed / max(1, args.steps)) / 1e9, 2),
+        }
+        # ---- CPU baseline: the reference's algorithm (kd-tree order) on the host cores, bounded sample
+        if not args.no_cpu_baseline:
+            from oracle import binding as ob
+
+            cores = min(16, os.cpu_count() or 1)
+            cpu = ob.OracleScene(scene.desc)
+            y0, y1 = 0, h  # the whole frame: ~3-4 s on 16 host cores (~1 core-minute of CPU work)
+            p = _abi.RenderParams(seed=0, x0=0, y0=y0, x1=w, y1=y1)
+            t0 = time.perf_counter()
+            _, _, n_cpu = cpu.render(p, mode=ob.MODE_KD, threads=cores, want_rgba=False)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": round(n_cpu / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"rows {y0}..{y1} of the same frame ({n_cpu} rays, {dt:.1f} s), oracle MODE_KD = C++ port of the reference "
+                          f"(SAH kd-tree, f64, std::thread over rows)",
+            }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

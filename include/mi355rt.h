@@ -184,7 +184,7 @@ typedef struct rt_render_stats {
     float ms_expand;  /* shade/expand (child + shadow ray emission)  */
     float ms_resolve; /* bottom-up shading resolve                   */
     float ms_accum;   /* per-pixel accumulate                        */
-    uint32_t _pad;
+    uint32_t retries; /* batches re-run smaller after a pool overflow */
 } rt_render_stats;
 
 typedef struct rt_scene rt_scene; /* opaque */
@@ -230,8 +230,16 @@ int rt_query_primary(rt_scene *scene, uint32_t *prim_id, double *t, double *norm
 int rt_trace_rays(rt_scene *scene, uint32_t n, const double *origin, const double *dir,
                   const double *tmax, int shadow, uint32_t *prim_id, double *t);
 
-/* BVH facts for reports: node count, leaf count, max depth, bytes resident. */
+/* BVH facts for reports: node count, leaf count, max depth, bytes resident,
+ * bounded / unbounded primitive counts, node / shadow pool capacities. */
 int rt_scene_info(rt_scene *scene, uint64_t *out8);
+
+/* The tile partition rt_render_device uses for `params` (pure host code, no
+ * GPU needed): writes up to `cap` tile origins (x,y pairs) to tile_xy and
+ * returns the tile count and tile extent.  Every rank of a multi-GPU job must
+ * see the same partition; tiles are dealt to shards in Morton order. */
+int rt_shard_tiles(const rt_render_options *opts, const rt_render_params *params, uint32_t *tile_xy,
+                   uint32_t cap, uint32_t *n_tiles, uint32_t *tile_w, uint32_t *tile_h);
 
 const char *rt_last_error(void);
 const char *rt_version(void);

@@ -140,7 +140,7 @@ class RenderStats(C.Structure):
         ("ms_expand", C.c_float),
         ("ms_resolve", C.c_float),
         ("ms_accum", C.c_float),
-        ("_pad", C.c_uint32),
+        ("retries", C.c_uint32),
     ]
 
     def as_dict(self):

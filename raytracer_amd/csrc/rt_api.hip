@@ -248,9 +248,8 @@ struct CallPlan {
     uint64_t total_items = 0;
 };
 
-// Tiles of the call, uploaded to d_tiles.  Unsharded: one tile = the window.
-int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStream_t stream) {
-    const rt_render_options &o = s->dev.opts;
+// Tile partition of a call (host only).  Unsharded: one tile = the window.
+int plan_tiles(const rt_render_options &o, const rt_render_params *prm, std::vector<uint32_t> *tiles_out, WorkList *wl_out) {
     rt_render_params p{};
     if (prm) p = *prm;
     uint32_t x0 = p.x0, y0 = p.y0, x1 = p.x1, y1 = p.y1, s0 = p.s0, s1 = p.s1;
@@ -265,8 +264,9 @@ int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStrea
     }
     if (x1 > o.width || y1 > o.height || x0 >= x1 || y0 >= y1 || s0 >= s1 || s1 > o.samples_per_pixel)
         return fail(RT_ERR_INVALID, "render window / sample range out of range");
-    std::vector<uint32_t> tiles;
-    WorkList &wl = plan->wl;
+    std::vector<uint32_t> &tiles = *tiles_out;
+    tiles.clear();
+    WorkList &wl = *wl_out;
     if (p.shard_count <= 1) {
         tiles = {x0, y0};
         wl.tile_w = x1 - x0;
@@ -297,6 +297,15 @@ int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStrea
     wl.s0 = s0;
     wl.ns = s1 - s0;
     wl.seed = p.seed;
+    wl.tile_xy = nullptr;
+    return RT_OK;
+}
+
+int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStream_t stream) {
+    std::vector<uint32_t> tiles;
+    WorkList &wl = plan->wl;
+    int prc = plan_tiles(s->dev.opts, prm, &tiles, &wl);
+    if (prc) return prc;
     plan->total_items = static_cast<uint64_t>(wl.n_tiles) * wl.tile_w * wl.tile_h * wl.ns;
     if (plan->total_items > 0xFFFFFFFFull) return fail(RT_ERR_INVALID, "more than 2^32 camera rays in one call");
     if (wl.n_tiles > s->d_tiles_cap) {
@@ -507,6 +516,24 @@ int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes) {
     return RT_OK;
 }
 
+int rt_shard_tiles(const rt_render_options *opts, const rt_render_params *params, uint32_t *tile_xy, uint32_t cap,
+                   uint32_t *n_tiles, uint32_t *tile_w, uint32_t *tile_h) {
+    if (!opts || !n_tiles) return fail(RT_ERR_INVALID, "null argument");
+    std::vector<uint32_t> tiles;
+    WorkList wl{};
+    int rc = plan_tiles(*opts, params, &tiles, &wl);
+    if (rc) return rc;
+    *n_tiles = wl.n_tiles;
+    if (tile_w) *tile_w = wl.tile_w;
+    if (tile_h) *tile_h = wl.tile_h;
+    if (tile_xy)
+        for (uint32_t i = 0; i < wl.n_tiles && i < cap; ++i) {
+            tile_xy[2 * i] = tiles[2 * i];
+            tile_xy[2 * i + 1] = tiles[2 * i + 1];
+        }
+    return RT_OK;
+}
+
 int rt_scene_info(rt_scene *scene, uint64_t *out8) {
     if (!scene || !out8) return fail(RT_ERR_INVALID, "null argument");
     out8[0] = scene->n_nodes;
@@ -609,6 +636,7 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
             if (n <= wl.ns) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's ray tree");
             batch = std::max<uint64_t>(wl.ns, (n / 2) - (n / 2) % wl.ns);
             s->est_nodes_per_item = 0.0;
+            st.retries += 1;
             continue;  // re-run the same range with a smaller batch; nothing was accumulated
         }
         // ---- statistics (reference counting rule: +1 per traced get_color/get_illumination, +1 per shadow ray)

@@ -32,6 +32,18 @@ def lib():
         path = lib_path()
         if not os.path.exists(path):
             raise DeviceError(f"{path} is missing: build it with __graft_entry__.build() (hipcc, gfx950)")
+        # PyTorch bundles its own HIP runtime.  If torch is going to be used in this
+        # process it must initialise that runtime BEFORE this library pulls in
+        # /opt/rocm's libamdhip64 (two runtimes in one process: torch then reports
+        # "No HIP GPUs are available").  torch is plumbing here, never required.
+        if os.environ.get("MI355RT_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch
+
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except Exception:
+                pass
         l = C.CDLL(path)
         vp, u32p, f64p, u8p, u64p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
         l.rt_scene_create.argtypes = [vp, C.POINTER(vp)]

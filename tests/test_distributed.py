@@ -1,0 +1,71 @@
+"""The N > 1 path on CPU: two `gloo` ranks render their tile / sample shards
+(the CPU oracle stands in for the GPU renderer -- same rt_render_params
+contract), one reduce(SUM) assembles the frame on rank 0.  On the GPU box
+bench.py runs the same raytracer_amd.distributed.render_frame over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_scene
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, sample_shards, out_path):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    from oracle import binding as ob
+    from raytracer_amd import distributed
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = load_scene("test", size=96)
+        o = ob.OracleScene(s.desc)
+        spp = s.opts.samples_per_pixel
+
+        def render_local(params, accum):
+            acc, _, count = o.render(params, mode=ob.MODE_CANONICAL, threads=2, want_rgba=False)
+            # the oracle renders a window per call: emulate the tile shard by masking to this rank's tiles
+            xy, tw, th = distributed.shard_tiles(s.opts, params)
+            mask = np.zeros(acc.shape[:2], bool)
+            for x, y in xy:
+                mask[y : y + th, x : x + tw] = True
+            accum += torch.from_numpy(acc * mask[..., None])
+            return count  # (count is for the whole window; only the image is checked for tile shards)
+
+        accum = torch.zeros((96, 96, 3), dtype=torch.float64)
+        total, local = distributed.render_frame(render_local, accum, rank, world, spp, seed=0, tile_size=16,
+                                                sample_shards=sample_shards, dist=dist)
+        if rank == 0:
+            np.save(out_path, accum.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sample_shards", [1, 2])
+def test_two_rank_gloo_frame_equals_single_rank(libs, tmp_path, sample_shards):
+    import torch.multiprocessing as mp
+
+    _, ob = libs
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(2, _free_port(), sample_shards, out), nprocs=2, join=True)
+    frame = np.load(out)
+    s = load_scene("test", size=96)
+    full, _, _ = ob.OracleScene(s.desc).render(mode=ob.MODE_CANONICAL, threads=4, want_rgba=False)
+    if sample_shards == 1:
+        assert np.array_equal(frame, full)  # tile shards: one non-zero contributor per pixel
+    else:
+        assert np.allclose(frame, full, rtol=0, atol=1e-12)  # sample shards: f64 re-association only

@@ -1,0 +1,249 @@
+"""Pins the CPU oracle (oracle/rt_oracle.cpp) to what the reference itself holds:
+its unit-test vectors (src/utils/mod.rs:55-83, src/utils/sampling.rs:79-189),
+its published ray counts (renders/renders.md) and its raw renders
+(renders/test.png etc., copied to tests/golden/renders/).  The Rust crate
+cannot be built in this image, so these are the strongest anchors available."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_scene
+
+
+def test_quadratic_known_answers(libs):
+    _, ob = libs
+    l = ob.lib()
+
+    def q(a, b, c):
+        t0, t1 = C.c_double(), C.c_double()
+        ok = l.orc_quadratic(a, b, c, C.byref(t0), C.byref(t1))
+        return (t0.value, t1.value) if ok else None
+
+    # utils/mod.rs:78-82
+    assert q(1.0, 2.0, 1.0) == (-1.0, -1.0)
+    assert q(1.0, -6.0, 9.0) == (3.0, 3.0)
+    assert q(4.0, 4.0, 1.0) == (-0.5, -0.5)
+    assert q(2.0, -25.0, 12.0) == (0.5, 12.0)
+    assert q(1.0, 1.0, 1.0) is None
+
+
+def test_remap_value_and_argb(libs):
+    _, ob = libs
+    l = ob.lib()
+    # utils/mod.rs:68-73
+    assert l.orc_remap_value(1.0, 0.0, 1.0, 0.0, 5.0) == 5.0
+    assert l.orc_remap_value(0.5, 0.0, 1.0, 0.0, 5.0) == 2.5
+    assert l.orc_remap_value(0.5, 0.0, 1.0, 0.0, 10.0) == 5.0
+    assert l.orc_remap_value(0.5, 0.0, 0.5, 0.0, 10.0) == 10.0
+    assert l.orc_remap_value(-1.0, 0.0, 1.0, 0.0, 10.0) == -10.0
+    assert l.orc_remap_value(2.0, 0.0, 1.0, 0.0, 10.0) == 20.0
+    # utils/mod.rs:56-63
+    a = 255 << 24
+    assert l.orc_to_argb_u32(0.0, 0.0, 0.0) == a
+    assert l.orc_to_argb_u32(1.0, 1.0, 1.0) == a | 255 << 16 | 255 << 8 | 255
+    assert l.orc_to_argb_u32(0.0, 0.0, 1.0) == a | 255
+    assert l.orc_to_argb_u32(1.0, 0.0, 1.0) == a | 255 << 16 | 255
+
+
+def test_philox_known_answers(libs):
+    """Random123 kat_vectors, philox4x32 10."""
+    _, ob = libs
+    l = ob.lib()
+
+    def ph(ctr, key):
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        l.orc_philox4x32_10(c, k, o)
+        return list(o)
+
+    assert ph([0] * 4, [0] * 2) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert ph([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert ph([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_uniform_stream_is_in_unit_interval_and_distinct(libs):
+    _, ob = libs
+    l = ob.lib()
+    seen = set()
+    out = (C.c_double * 2)()
+    path = 0
+    for i in range(2000):
+        path = l.orc_path_mix(path, i % 7)
+        l.orc_uniforms2(0, i, i % 4, path, out)
+        assert 0.0 <= out[0] < 1.0 and 0.0 <= out[1] < 1.0
+        seen.add((out[0], out[1]))
+    assert len(seen) == 2000
+
+
+def _angle(a, b):
+    a = np.asarray(a) / np.linalg.norm(a)
+    b = np.asarray(b) / np.linalg.norm(b)
+    return math.acos(max(-1.0, min(1.0, float(a @ b))))
+
+
+def test_cosine_hemisphere_stays_in_hemisphere(libs):
+    """sampling.rs:79-88: 10 000 draws within pi/2 + 1e-6 of the axis."""
+    _, ob = libs
+    l = ob.lib()
+    rng = np.random.default_rng(1)
+    out = (C.c_double * 3)()
+    for _ in range(10000):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        u1, u2 = rng.random(2)
+        l.orc_cosine_sample_hemisphere((C.c_double * 3)(*d), u1, u2, out)
+        v = np.array(out[:])
+        assert abs(np.linalg.norm(v) - 1.0) < 1e-12
+        assert _angle(v, d) <= math.pi / 2 + 1e-6
+
+
+@pytest.mark.parametrize("case", ["random", "plus_z", "minus_z", "zero_angle", "half_pi"])
+def test_uniform_sample_cone_stays_in_cone(libs, case):
+    """sampling.rs:91-189."""
+    _, ob = libs
+    l = ob.lib()
+    rng = np.random.default_rng(2)
+    out = (C.c_double * 3)()
+    for _ in range(10000):
+        if case in ("plus_z", "minus_z"):
+            d = np.array([0.0, 0.0, 1.0 if case == "plus_z" else -1.0])
+        else:
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+        max_angle = {"zero_angle": 0.0, "half_pi": math.pi / 2}.get(case, rng.random() * math.pi / 2)
+        u1, u2 = rng.random(2)
+        l.orc_uniform_sample_cone((C.c_double * 3)(*d), max_angle, u1, u2, out)
+        v = np.array(out[:])
+        assert _angle(v, d) <= max_angle + 1e-6
+        if case == "zero_angle":
+            assert np.array_equal(v, d)
+
+
+def test_reflect_refract(libs):
+    _, ob = libs
+    l = ob.lib()
+    arr = lambda v: (C.c_double * 3)(*v)
+    out = (C.c_double * 3)()
+    l.orc_reflect(arr([1, -1, 0]), arr([0, 1, 0]), out)
+    assert np.allclose(out[:], np.array([1, 1, 0]) / math.sqrt(2), atol=1e-15)
+    assert l.orc_refract(arr([0, -1, 0]), arr([0, 1, 0]), 1.0 / 1.5, out) == 1
+    assert np.allclose(out[:], [0, -1, 0], atol=1e-15)
+    # total internal reflection: leaving a dense medium at a grazing angle (n.i >= 0 -> eta inverted)
+    i = np.array([math.sin(1.2), math.cos(1.2), 0.0])
+    assert l.orc_refract(arr(i), arr([0, 1, 0]), 1.0 / 1.5, out) == 0
+
+
+def test_tonemap_truncates(libs):
+    """raytracing_scene.rs:614-621, :765-767: /spp, clamp, ^(1/2.2), `as u8` truncation."""
+    _, ob = libs
+    l = ob.lib()
+    out = (C.c_uint8 * 4)()
+    l.orc_tonemap((C.c_double * 3)(4.0, 2.0, 0.0), 4, out)
+    assert list(out) == [255, int(255.0 * 0.5 ** (1 / 2.2)), 0, 255]
+    l.orc_tonemap((C.c_double * 3)(9.0, -1.0, float("nan")), 4, out)
+    assert list(out) == [255, 0, 0, 255]
+
+
+with open(os.path.join(GOLDEN, "ray_counts.json")) as _f:
+    RAY_COUNTS = json.load(_f)
+
+
+@pytest.mark.parametrize("name", ["test", "emissive", "occlusion", "mesh", "refraction", "scene"])
+def test_full_size_ray_count_matches_published(libs, name):
+    """renders/renders.md publishes rays per scene (3-run averages, thread_rng):
+    the restatement of the whole branching logic must land within 0.1 %.
+    (physical.json, 534 M rays, is checked by tools/make_golden.py and the
+    committed ray_counts.json: +0.0074 %.)"""
+    _, ob = libs
+    s = load_scene(name)
+    o = ob.OracleScene(s.desc)
+    _, _, count = o.render(mode=ob.MODE_KD, threads=8, want_rgba=False)
+    pub = RAY_COUNTS[name]["published"]
+    assert abs(count - pub) / pub < 1e-3, (count, pub)
+    assert count == RAY_COUNTS[name]["oracle_kd"]
+
+
+def test_committed_ray_counts_are_within_tolerance():
+    for name, c in RAY_COUNTS.items():
+        assert abs(c["oracle_kd"] - c["published"]) / c["published"] < 1e-3, name
+        assert abs(c["oracle_canonical"] - c["oracle_kd"]) / c["oracle_kd"] < 1e-6, name
+
+
+def _block_mean(img, b=8):
+    h, w, _ = img.shape
+    return img.reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))
+
+
+@pytest.mark.parametrize("name,tol", [("test", 4.0)])
+def test_render_matches_reference_png_statistically(libs, name, tol):
+    """renders/test.png is raw tracer output (skip_denoise_pass) at 4 spp with an
+    unknown RNG stream: compare 8x8 block means (RMSE in 8-bit levels) and the
+    silhouette of the background."""
+    from PIL import Image
+
+    _, ob = libs
+    s = load_scene(name)
+    o = ob.OracleScene(s.desc)
+    _, rgba, _ = o.render(mode=ob.MODE_KD, threads=8)
+    ref = np.array(Image.open(os.path.join(GOLDEN, "renders", f"{name}.png")).convert("RGB")).astype(np.float64)
+    ours = rgba[..., :3].astype(np.float64)
+    d = _block_mean(ours) - _block_mean(ref)
+    assert math.sqrt(float((d ** 2).mean())) < tol
+    assert abs(ours.mean() - ref.mean()) < 1.0
+    # silhouette against the black sky (rows above the horizon): the sheared cube of quirk Q1 and a sphere
+    fg_ref, fg_ours = ref[:300].sum(axis=2) > 0, ours[:300].sum(axis=2) > 0
+    iou = (fg_ref & fg_ours).sum() / max(1, (fg_ref | fg_ours).sum())
+    assert iou > 0.97  # the rest is the 1-pixel fringe of randomly jittered edge samples
+
+
+SMALL = ["test", "scene", "mesh", "refraction", "physical", "cornell_box", "occlusion", "emissive"]
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_small_fixture_is_reproduced_and_modes_agree(libs, name):
+    """tests/golden/oracle_<scene>.npz (tools/make_golden.py): the oracle must
+    reproduce its committed 64x64 output bit for bit; kd (reference traversal
+    order), canonical and brute-force semantics must agree outside exact ties
+    (cornell_box has a coplanar light/ceiling, quirk Q17)."""
+    _, ob = libs
+    g = np.load(os.path.join(GOLDEN, f"oracle_{name}.npz"))
+    s = load_scene(name, size=64)
+    o = ob.OracleScene(s.desc)
+    ids, t, nrm = o.query_primary(ob.MODE_CANONICAL)
+    assert np.array_equal(ids, g["ids"]) and np.array_equal(t, g["t"]) and np.array_equal(nrm, g["normals"])
+    acc, rgba, count = o.render(mode=ob.MODE_CANONICAL, threads=8)
+    assert count == int(g["ray_count"])
+    assert np.array_equal(acc, g["accum"]) and np.array_equal(rgba, g["rgba"])
+    ids_b, t_b, _ = o.query_primary(ob.MODE_BRUTE)
+    assert np.array_equal(ids_b, ids) and np.array_equal(t_b, t)
+    ids_k, _, _ = o.query_primary(ob.MODE_KD)
+    mismatch = int((ids_k != ids).sum())
+    assert mismatch == 0 or (name == "cornell_box" and mismatch < 0.01 * ids.size)
+    if name in ("test", "occlusion", "emissive", "cornell_box"):
+        acc_b, _, count_b = o.render(mode=ob.MODE_BRUTE, threads=8, want_rgba=False)
+        assert count_b == count and np.array_equal(acc_b, acc)
+
+
+def test_window_and_sample_ranges_compose(libs):
+    """rt_render_params contract on the oracle side: windows tile the frame,
+    sample ranges add up (up to f64 re-association)."""
+    from raytracer_amd._abi import RenderParams
+
+    _, ob = libs
+    s = load_scene("test", size=48)
+    o = ob.OracleScene(s.desc)
+    full, _, n_full = o.render(mode=ob.MODE_CANONICAL, threads=4, want_rgba=False)
+    acc = np.zeros_like(full)
+    n = 0
+    for (x0, x1) in ((0, 17), (17, 48)):
+        a, _, c = o.render(RenderParams(x0=x0, y0=0, x1=x1, y1=48), mode=ob.MODE_CANONICAL, threads=4, want_rgba=False)
+        acc += a
+        n += c
+    assert n == n_full and np.array_equal(acc, full)
+    a0, _, c0 = o.render(RenderParams(s0=0, s1=1), mode=ob.MODE_CANONICAL, threads=4, want_rgba=False)
+    a1, _, c1 = o.render(RenderParams(s0=1, s1=4), mode=ob.MODE_CANONICAL, threads=4, want_rgba=False)
+    assert c0 + c1 == n_full and np.allclose(a0 + a1, full, rtol=0, atol=1e-12)
