@@ -573,6 +573,7 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
     }
 
     uint64_t item0 = 0;
+    double call_max_nodes = 0.0, call_max_shadows = 0.0;
     // first batch: modest guess, later batches sized from the measured expansion
     uint64_t batch = std::min<uint64_t>(plan.total_items, std::max<uint64_t>(wl.ns, np.capacity / 96));
     if (s->est_nodes_per_item > 0.0) {
@@ -661,12 +662,21 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
         st.launches_shadow += cls_n[CLS_SHADOW];
         st.launches_other += cls_n[CLS_RAYGEN] + cls_n[CLS_EXPAND] + cls_n[CLS_RESOLVE] + cls_n[CLS_ACCUM] + cls_n[CLS_MISC];
 
-        s->est_nodes_per_item = static_cast<double>(c.node_alloc) / static_cast<double>(n);
-        s->est_shadows_per_item = static_cast<double>(c.shadow_alloc) / static_cast<double>(n);
+        // expansion varies over the image: size later batches (and later calls) from the
+        // LARGEST expansion seen, not the last one, so a cheap final batch cannot
+        // provoke an overflow + re-run at the start of the next frame
+        call_max_nodes = std::max(call_max_nodes, static_cast<double>(c.node_alloc) / static_cast<double>(n));
+        call_max_shadows = std::max(call_max_shadows, static_cast<double>(c.shadow_alloc) / static_cast<double>(n));
+        s->est_nodes_per_item = std::max(s->est_nodes_per_item, call_max_nodes);
+        s->est_shadows_per_item = std::max(s->est_shadows_per_item, call_max_shadows);
         double fit = std::min(np.capacity / std::max(s->est_nodes_per_item, 1.0),
                               sp.capacity / std::max(s->est_shadows_per_item, 1e-9));
         batch = std::max<uint64_t>(wl.ns, static_cast<uint64_t>(0.7 * fit));
         item0 += n;
+    }
+    if (call_max_nodes > 0.0) {  // forget stale maxima of earlier calls (other windows / shards)
+        s->est_nodes_per_item = call_max_nodes;
+        s->est_shadows_per_item = call_max_shadows;
     }
     st.ray_count = st.closest_rays + st.shadow_rays;
     if (stats) {
