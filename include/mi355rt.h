@@ -196,7 +196,7 @@ typedef struct rt_scene rt_scene; /* opaque */
 int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_destroy(rt_scene *scene);
 
-/* Limit the device memory used for wavefront pools (default 8 GiB). */
+/* Limit the device memory used for wavefront pools (default 24 GiB, allocated at the first render). */
 int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes);
 
 /* Replaces the pixel loop of raytrace_to_image

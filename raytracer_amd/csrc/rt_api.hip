@@ -165,7 +165,7 @@ struct rt_scene {
     uint64_t n_nodes = 0, n_leaves = 0, bvh_depth = 0;
     int n_cus = 256;
 
-    uint64_t pool_bytes = 8ull << 30;
+    uint64_t pool_bytes = 24ull << 30;  // one batch for 800x800x4spp scene.json (108 M nodes); 8 % of the 288 GB
     void *pool_mem = nullptr;
     uint64_t pool_mem_bytes = 0;
     NodePool np{};
@@ -237,8 +237,8 @@ int ensure_pools(rt_scene *s) {
     sp.capacity = static_cast<uint32_t>(scap);
     if (static_cast<uint64_t>(p - static_cast<char *>(s->pool_mem)) > s->pool_bytes)
         return fail(RT_ERR_NOMEM, "internal: pool carve exceeds budget");
-    if (!s->d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ctr), sizeof(Counters)));
-    if (!s->h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctr), sizeof(Counters)));
+    if (!s->d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ctr), MAX_SHARDS * sizeof(Counters)));
+    if (!s->h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctr), MAX_SHARDS * sizeof(Counters)));
     s->est_nodes_per_item = s->est_shadows_per_item = 0.0;
     return RT_OK;
 }
@@ -328,6 +328,28 @@ uint32_t grid_for(const rt_scene *s, uint64_t n, uint32_t blocks_per_cu) {
     return static_cast<uint32_t>(std::max<uint64_t>(1, std::min(need, cap)));
 }
 
+// grid of a sharded launch: a multiple of the shard count (kernels derive the shard from blockIdx.x)
+uint32_t shard_grid(const rt_scene *s, const Shards &sh, uint64_t n, uint32_t blocks_per_cu) {
+    const uint32_t g = grid_for(s, n, blocks_per_cu);
+    return ((g + sh.count - 1) / sh.count) * sh.count;
+}
+
+// Shard layout of a batch of n camera-ray items (ns samples per pixel).
+Shards plan_shards(const rt_scene *s, uint64_t n, uint32_t ns) {
+    Shards sh{};
+    sh.granule = 64u * ns;  // 64 consecutive pixels per deal
+    const uint64_t n_gran = (n + sh.granule - 1) / sh.granule;
+    uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(MAX_SHARDS, std::max<uint64_t>(1, n_gran / 4)));
+    if (k >= 8) k &= ~7u;  // whole shards per XCD (blocks are dealt round-robin over the 8 XCDs)
+    sh.count = k;
+    if (k == 1) sh.granule = ns;  // no padding items in small batches
+    sh.node_cap = s->np.capacity / k;
+    sh.shadow_cap = s->sp.capacity / k;
+    return sh;
+}
+
+Shards single_shard(const rt_scene *s) { return Shards{1u, s->np.capacity, s->sp.capacity, 1u}; }
+
 }  // namespace
 
 extern "C" {
@@ -346,6 +368,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         return fail(RT_ERR_UNSUPPORTED, "max_depth > 6: 8_u16.pow(depth) overflows in the reference");
     if (o.samples_per_pixel > 65535 || o.max_reflected_rays > 65535 || o.max_illumination_rays > 65535)
         return fail(RT_ERR_INVALID, "u16 option out of range");
+    if (o.max_illumination_rays > 16383) return fail(RT_ERR_UNSUPPORTED, "max_illumination_rays > 16383");
     if (d->n_lights > 255) return fail(RT_ERR_UNSUPPORTED, "more than 255 lights");
     if (d->n_materials >= (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "too many materials");
     uint32_t n_point = 0;
@@ -587,49 +610,62 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
         n -= n % wl.ns;
         if (n == 0) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's samples");
         const uint32_t n32 = static_cast<uint32_t>(n), i0 = static_cast<uint32_t>(item0);
+        const Shards sh = plan_shards(s, n, wl.ns);
+        const uint32_t g_level = shard_grid(s, sh, static_cast<uint64_t>(s->n_cus) * 4u * BLOCK, 4);
+        const uint32_t g_wide = shard_grid(s, sh, static_cast<uint64_t>(gmax) * BLOCK, 8);
 
         timer.begin(CLS_MISC);
-        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, stream, s->d_ctr, n32);
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, stream, s->d_ctr, sh, n32);
         timer.end();
         timer.begin(CLS_RAYGEN);
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, s->d_ctr, i0, n32);
+        hipLaunchKernelGGL(k_raygen, dim3(shard_grid(s, sh, n, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, s->d_ctr, sh, i0, n32);
         timer.end();
         if (max_depth > 0) {
             for (uint32_t level = 0; level < max_depth; ++level) {
-                const uint32_t g = level == 0 ? grid_for(s, n, 4) : static_cast<uint32_t>(s->n_cus) * 4u;
+                const uint32_t g = level == 0 ? shard_grid(s, sh, n, 4) : g_level;
                 timer.begin(CLS_CLOSEST);
-                if (count_work) hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(BLOCK), 0, stream, s->dev, np, s->d_ctr, level);
-                else hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(BLOCK), 0, stream, s->dev, np, s->d_ctr, level);
+                if (count_work) hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(BLOCK), 0, stream, s->dev, np, s->d_ctr, sh, level);
+                else hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(BLOCK), 0, stream, s->dev, np, s->d_ctr, sh, level);
                 timer.end();
                 timer.begin(CLS_EXPAND);
-                hipLaunchKernelGGL(k_expand, dim3(level == 0 ? grid_for(s, n, 8) : gmax), dim3(BLOCK), 0, stream, s->dev, wl, np, sp,
-                                   s->d_ctr, level);
-                hipLaunchKernelGGL(k_advance_level, dim3(1), dim3(64), 0, stream, s->d_ctr, level, np.capacity, sp.capacity);
+                hipLaunchKernelGGL(k_expand, dim3(level == 0 ? shard_grid(s, sh, n, 8) : g_wide), dim3(BLOCK), 0, stream, s->dev, wl, np,
+                                   sp, s->d_ctr, sh, level);
+                hipLaunchKernelGGL(k_advance_level, dim3(1), dim3(64), 0, stream, s->d_ctr, sh, level);
                 timer.end();
             }
             timer.begin(CLS_SHADOW);
             if (count_work)
-                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(static_cast<uint32_t>(s->n_cus) * 4u), dim3(BLOCK), 0, stream,
-                                   s->dev, np, sp, s->d_ctr, 0u);
+                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(g_level), dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, 0u);
             else
-                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(static_cast<uint32_t>(s->n_cus) * 4u), dim3(BLOCK), 0, stream,
-                                   s->dev, np, sp, s->d_ctr, 0u);
+                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(g_level), dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, 0u);
             timer.end();
             for (uint32_t level = max_depth; level-- > 0;) {
                 timer.begin(CLS_RESOLVE);
-                hipLaunchKernelGGL(k_resolve, dim3(level == 0 ? grid_for(s, n, 8) : gmax), dim3(BLOCK), 0, stream, s->dev, np, sp,
-                                   s->d_ctr, level);
+                hipLaunchKernelGGL(k_resolve, dim3(level == 0 ? shard_grid(s, sh, n, 8) : g_wide), dim3(BLOCK), 0, stream, s->dev, np, sp,
+                                   s->d_ctr, sh, level);
                 timer.end();
             }
             timer.begin(CLS_ACCUM);
-            hipLaunchKernelGGL(k_accumulate, dim3(grid_for(s, n / wl.ns, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, s->d_ctr, i0,
-                               n32, d_rgb_accum);
+            hipLaunchKernelGGL(k_accumulate, dim3(shard_grid(s, sh, n / wl.ns, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, s->d_ctr, sh,
+                               d_rgb_accum);
             timer.end();
         }
-        HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, sh.count * sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
-        const Counters &c = *s->h_ctr;
+        Counters c{};  // sum over shards
+        for (uint32_t k = 0; k < sh.count; ++k) {
+            const Counters &ck = s->h_ctr[k];
+            for (uint32_t l = 0; l <= MAX_LEVELS; ++l) c.level_count[l] += ck.level_count[l];
+            c.node_alloc += ck.node_alloc;
+            c.shadow_alloc += ck.shadow_alloc;
+            c.overflow |= ck.overflow;
+            c.active_camera += ck.active_camera;
+            c.nodes_visited_closest += ck.nodes_visited_closest;
+            c.prims_tested_closest += ck.prims_tested_closest;
+            c.nodes_visited_shadow += ck.nodes_visited_shadow;
+            c.prims_tested_shadow += ck.prims_tested_shadow;
+        }
         float cls_ms[CLS_COUNT] = {0};
         uint32_t cls_n[CLS_COUNT] = {0};
         timer.collect(cls_ms, cls_n, CLS_COUNT);
@@ -754,12 +790,14 @@ int rt_query_primary(rt_scene *s, uint32_t *prim_id, double *t, double *normal3)
     uint64_t item0 = 0;
     while (item0 < plan.total_items) {
         const uint32_t n = static_cast<uint32_t>(std::min<uint64_t>(plan.total_items - item0, s->np.capacity));
-        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, n);
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, s->d_ctr,
+        const Shards one = single_shard(s);
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, one, n);
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, s->d_ctr, one,
                            static_cast<uint32_t>(item0), n);
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, n, 4)), dim3(BLOCK), 0, nullptr, s->dev, s->np, s->d_ctr, 0u);
-        hipLaunchKernelGGL(k_primary_aov, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np,
-                           static_cast<uint32_t>(item0), n, d_id, d_t, d_n);
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, n, 4)), dim3(BLOCK), 0, nullptr, s->dev, s->np, s->d_ctr, one,
+                           0u);
+        hipLaunchKernelGGL(k_primary_aov, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, n, d_id, d_t,
+                           d_n);
         item0 += n;
     }
     hipError_t e = hipDeviceSynchronize();
@@ -797,13 +835,15 @@ int rt_trace_rays(rt_scene *s, uint32_t n, const double *origin, const double *d
         HIP_TRY(put(np.dz, dir, 2));
         meta.assign(m, 1u);  // depth 1 secondary
         HIP_TRY(hipMemcpy(np.meta, meta.data(), m * 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, m);
+        const Shards one = single_shard(s);
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, one, m);
         if (shadow) {
             HIP_TRY(hipMemcpy(np.t, tmax + done, m * sizeof(double), hipMemcpyHostToDevice));
             hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid_for(s, m, 4)), dim3(BLOCK), 0, nullptr, s->dev, np, s->sp,
-                               s->d_ctr, m);
+                               s->d_ctr, one, m);
         } else {
-            hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, m, 4)), dim3(BLOCK), 0, nullptr, s->dev, np, s->d_ctr, 0u);
+            hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, m, 4)), dim3(BLOCK), 0, nullptr, s->dev, np, s->d_ctr, one,
+                               0u);
         }
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(prim_id + done, np.prim, m * 4, hipMemcpyDeviceToHost));

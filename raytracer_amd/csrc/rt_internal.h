@@ -159,6 +159,21 @@ struct Counters {
     unsigned long long nodes_visited_shadow, prims_tested_shadow;
 };
 
+// The wavefront pools are split into `count` shards.  A shard is an independent
+// sub-batch: its own bump allocators (Counters), its own slice of the node and
+// shadow pools, its own camera rays (granules of `granule` items dealt round-robin,
+// so every shard samples the whole image) and its own thread blocks
+// (blockIdx.x % count; with count a multiple of 8 a shard stays on one XCD, whose
+// L2 then holds what the shard wrote).  One allocator word per shard instead of one
+// per batch: a single word saturates at ~90 returning atomics per microsecond.
+constexpr uint32_t MAX_SHARDS = 64;
+struct Shards {
+    uint32_t count;
+    uint32_t node_cap;    // nodes per shard
+    uint32_t shadow_cap;  // shadow rays per shard
+    uint32_t granule;     // camera-ray items per deal (multiple of the samples per pixel)
+};
+
 // One call's work list: tiles of tile_w x tile_h pixels, ns samples each.
 struct WorkList {
     const uint32_t *tile_xy;  // [n_tiles*2] tile origin (pixels)

@@ -42,6 +42,28 @@ __device__ __forceinline__ void item_to_pixel(const WorkList &wl, uint32_t item,
     *sample = wl.s0 + s_local;
 }
 
+struct ShardCtx {
+    Counters *ctr;
+    uint32_t node_off, shadow_off;  // first pool index of the shard
+    uint32_t bid, nblocks;          // this block's index / the block count within the shard
+    uint32_t shard;
+};
+// gridDim.x is a multiple of sh.count (host guarantees)
+__device__ __forceinline__ ShardCtx shard_ctx(Counters *ctrs, const Shards &sh) {
+    ShardCtx c;
+    c.shard = blockIdx.x % sh.count;
+    c.ctr = ctrs + c.shard;
+    c.node_off = c.shard * sh.node_cap;
+    c.shadow_off = c.shard * sh.shadow_cap;
+    c.bid = blockIdx.x / sh.count;
+    c.nblocks = gridDim.x / sh.count;
+    return c;
+}
+// batch-relative item of a shard's j-th camera ray
+__device__ __forceinline__ uint32_t shard_item(const Shards &sh, uint32_t shard, uint32_t j) {
+    return ((j / sh.granule) * sh.count + shard) * sh.granule + j % sh.granule;
+}
+
 // Wave-aggregated bump allocation: every lane of the wave must call it.
 __device__ __forceinline__ uint64_t wave_alloc(unsigned long long *counter, uint32_t n, uint32_t *wave_total) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -167,41 +189,54 @@ __device__ __forceinline__ d3 light_radiance(const DLight &l, double dist) {
 }
 
 // ------------------------------------------------------------------ batch bookkeeping
-__global__ void k_begin_batch(Counters *ctr, uint32_t n_items) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        for (uint32_t i = 0; i <= MAX_LEVELS; ++i) {
-            ctr->level_start[i] = 0;
-            ctr->level_count[i] = 0;
-        }
-        ctr->level_count[0] = n_items;
-        ctr->node_alloc = n_items;
-        ctr->shadow_alloc = 0;
-        ctr->overflow = 0;
-        ctr->active_camera = 0;
-        ctr->nodes_visited_closest = ctr->prims_tested_closest = 0;
-        ctr->nodes_visited_shadow = ctr->prims_tested_shadow = 0;
+__global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
+    const uint32_t k = threadIdx.x;
+    if (blockIdx.x != 0 || k >= sh.count) return;
+    Counters *ctr = ctrs + k;
+    const uint32_t n_gran = (n_items + sh.granule - 1) / sh.granule;
+    const uint32_t local = (n_gran / sh.count + (k < n_gran % sh.count ? 1u : 0u)) * sh.granule;
+    for (uint32_t i = 0; i <= MAX_LEVELS; ++i) {
+        ctr->level_start[i] = 0;
+        ctr->level_count[i] = 0;
     }
+    ctr->level_count[0] = local;  // items past n_items are padding (META_INACTIVE)
+    ctr->node_alloc = local;
+    ctr->shadow_alloc = 0;
+    ctr->overflow = local > sh.node_cap ? 1u : 0u;
+    ctr->active_camera = 0;
+    ctr->nodes_visited_closest = ctr->prims_tested_closest = 0;
+    ctr->nodes_visited_shadow = ctr->prims_tested_shadow = 0;
 }
 
-__global__ void k_advance_level(Counters *ctr, uint32_t level, uint32_t node_cap, uint32_t shadow_cap) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t start = ctr->level_start[level] + ctr->level_count[level];
-        if (ctr->node_alloc > node_cap || ctr->shadow_alloc > shadow_cap) ctr->overflow = 1;
-        ctr->level_start[level + 1] = start;
-        ctr->level_count[level + 1] = ctr->overflow ? 0u : static_cast<uint32_t>(ctr->node_alloc) - start;
-    }
+__global__ void k_advance_level(Counters *ctrs, Shards sh, uint32_t level) {
+    const uint32_t k = threadIdx.x;
+    if (blockIdx.x != 0 || k >= sh.count) return;
+    Counters *ctr = ctrs + k;
+    uint32_t start = ctr->level_start[level] + ctr->level_count[level];
+    if (ctr->node_alloc > sh.node_cap || ctr->shadow_alloc > sh.shadow_cap) ctr->overflow = 1;
+    ctr->level_start[level + 1] = start;
+    ctr->level_count[level + 1] = ctr->overflow ? 0u : static_cast<uint32_t>(ctr->node_alloc) - start;
 }
 
 // ------------------------------------------------------------------ ray generation
-__global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev sc, WorkList wl, NodePool np, Counters *ctr,
+__global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev sc, WorkList wl, NodePool np, Counters *ctrs, Shards shards,
                                                  uint32_t item0, uint32_t n_items) {
+    const ShardCtx c = shard_ctx(ctrs, shards);
+    Counters *ctr = c.ctr;
+    if (ctr->overflow) return;
+    const uint32_t n_local = ctr->level_count[0];
     const double width = static_cast<double>(sc.opts.width), height = static_cast<double>(sc.opts.height);
     const double aspect = width / height;
     uint32_t n_active = 0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_items; i += gridDim.x * BLOCK) {
-        uint32_t item = item0 + i, px, py, sample;
-        item_to_pixel(wl, item, &px, &py, &sample);
-        bool active = px >= wl.x0 && px < wl.x1 && py >= wl.y0 && py < wl.y1;
+    for (uint32_t j = c.bid * BLOCK + threadIdx.x; j < n_local; j += c.nblocks * BLOCK) {
+        const uint32_t i = c.node_off + j;
+        const uint32_t rel = shard_item(shards, c.shard, j);
+        uint32_t item = item0 + rel, px = 0, py = 0, sample = 0;
+        bool active = rel < n_items;
+        if (active) {
+            item_to_pixel(wl, item, &px, &py, &sample);
+            active = px >= wl.x0 && px < wl.x1 && py >= wl.y0 && py < wl.y1;
+        }
         np.root[i] = item;
         np.path[i] = 0ull;
         np.meta[i] = active ? 0u : META_INACTIVE;
@@ -268,12 +303,15 @@ __device__ __forceinline__ double cull_limit(double t) { return t + 1e-9 * (1.0 
 // KdTreeAccelerator::raycast semantics, traversal-order independent form
 // (DESIGN.md "canonical hit"): minimum of (t, bounded?, primitive id).
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, NodePool np, Counters *ctr, uint32_t level) {
+__global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, NodePool np, Counters *ctrs, Shards shards,
+                                                        uint32_t level) {
     __shared__ uint32_t stack[STACK_DEPTH * BLOCK];
+    const ShardCtx c = shard_ctx(ctrs, shards);
+    Counters *ctr = c.ctr;
     if (ctr->overflow) return;
-    const uint32_t start = ctr->level_start[level], count = ctr->level_count[level];
+    const uint32_t start = c.node_off + ctr->level_start[level], count = ctr->level_count[level];
     unsigned long long n_nodes = 0, n_prims = 0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+    for (uint32_t i = c.bid * BLOCK + threadIdx.x; i < count; i += c.nblocks * BLOCK) {
         const uint32_t idx = start + i;
         if (np.meta[idx] & META_INACTIVE) {
             np.prim[idx] = RT_NO_HIT;
@@ -368,13 +406,16 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, NodePool n
 // KdTreeAccelerator::shadow_cast semantics: OR over primitives within max_distance.
 // PROBE: rays come from the node pool (rt_trace_rays) instead of the shadow pool.
 template <bool COUNT, bool PROBE>
-__global__ __launch_bounds__(BLOCK) void k_trace_shadow(SceneDev sc, NodePool np, ShadowPool sp_pool, Counters *ctr,
-                                                       uint32_t probe_count) {
+__global__ __launch_bounds__(BLOCK) void k_trace_shadow(SceneDev sc, NodePool np, ShadowPool sp_pool, Counters *ctrs,
+                                                       Shards shards, uint32_t probe_count) {
     __shared__ uint32_t stack[STACK_DEPTH * BLOCK];
+    const ShardCtx c = shard_ctx(ctrs, shards);
+    Counters *ctr = c.ctr;
     if (ctr->overflow) return;
     const uint32_t count = PROBE ? probe_count : static_cast<uint32_t>(ctr->shadow_alloc);
     unsigned long long n_nodes = 0, n_prims = 0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+    for (uint32_t i0 = c.bid * BLOCK + threadIdx.x; i0 < count; i0 += c.nblocks * BLOCK) {
+        const uint32_t i = (PROBE ? c.node_off : c.shadow_off) + i0;
         RayD ray;
         double tmax;
         if (PROBE) {
@@ -453,36 +494,70 @@ __global__ __launch_bounds__(BLOCK) void k_trace_shadow(SceneDev sc, NodePool np
 // ------------------------------------------------------------------ expand
 // Emits the child rays and shadow rays of every node of `level`.
 // Child block layout of a node: [reflection x nR][refraction x nT][GI x nG].
-__global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, Counters *ctr,
-                                                 uint32_t level) {
+//
+// Two phases per 64 parents (one wave):
+//   A  one parent per lane: compute_data, child / shadow-ray counts, wave-wide
+//      bump allocation; the parent's shading context goes to LDS (SoA by thread).
+//   B  one CHILD per lane: lane j of the wave's contiguous child block finds its
+//      parent by binary search over the wave's inclusive prefix sums, draws its
+//      own sample and stores its ray -> every store instruction writes 64
+//      consecutive records (phase A's per-parent loops wrote 64 strided ones and
+//      left lanes of missed rays idle).  Same for the shadow rays.
+// Child order (parent-major, slot-minor) and RNG keys are unchanged.
+struct ExpandLds {
+    double Px[BLOCK], Py[BLOCK], Pz[BLOCK];     // hit point
+    double nx[BLOCK], ny[BLOCK], nz[BLOCK];     // shading normal
+    double rx[BLOCK], ry[BLOCK], rz[BLOCK];     // mirror direction
+    double tx[BLOCK], ty[BLOCK], tz[BLOCK];     // refraction direction
+    double max_angle[BLOCK];                    // cone half-angle (physical)
+    uint64_t path[BLOCK];
+    uint32_t root[BLOCK], pixel[BLOCK], sample[BLOCK];
+    uint32_t counts[BLOCK];                     // nR | nT << 16 | nG << 17 | phong << 31
+    uint32_t meta_same[BLOCK], meta_refr[BLOCK];
+    uint32_t mask[BLOCK];                       // point lights that get a shadow ray
+    uint32_t incl_nodes[BLOCK], incl_shadows[BLOCK];
+};
+
+// first p in [0,64) with incl[p] > j (incl = inclusive prefix sums of one wave)
+__device__ __forceinline__ uint32_t wave_owner(const uint32_t *incl, uint32_t j) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 32; step >= 1; step >>= 1)
+        if (incl[lo + step - 1] <= j) lo += step;
+    return lo;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, Counters *ctrs,
+                                                 Shards shards, uint32_t level) {
+    __shared__ ExpandLds L;
+    const ShardCtx c = shard_ctx(ctrs, shards);
+    Counters *ctr = c.ctr;
     if (ctr->overflow) return;
-    const uint32_t start = ctr->level_start[level], count = ctr->level_count[level];
+    const uint32_t start = c.node_off + ctr->level_start[level], count = ctr->level_count[level];
     const bool next_real = level + 1 < sc.opts.max_depth;
-    for (uint32_t base_i = blockIdx.x * BLOCK; base_i < count; base_i += gridDim.x * BLOCK) {
-        const uint32_t i = base_i + threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
+    const uint32_t child_depth = level + 1;
+    for (uint32_t base_i = c.bid * BLOCK; base_i < count; base_i += c.nblocks * BLOCK) {
+        const uint32_t i = base_i + tid;
         const bool valid = i < count;
         const uint32_t idx = start + (valid ? i : 0u);
-        uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0;
+        uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0, phong_flag = 0;
         uint32_t prim = RT_NO_HIT, meta = 0;
-        d3 o{}, d{};
-        Surface s{};
-        ShadePrim sh{};
-        rt_material m{};
-        d3 refr_dir{};
-        bool illum = false;
         if (valid) {
             meta = np.meta[idx];
             prim = (meta & META_INACTIVE) ? RT_NO_HIT : np.prim[idx];
         }
         if (prim != RT_NO_HIT) {
-            illum = (meta & META_ILLUM) != 0;
-            o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
-            d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
-            sh = sc.shade_prims[prim];
-            m = sc.materials[sh.material];
-            s = compute_surface(sc, sh, m.side, o, d, np.t[idx], np.bu[idx], np.bv[idx]);
+            const bool illum = (meta & META_ILLUM) != 0;
+            const d3 o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
+            const d3 d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
+            const ShadePrim sh = sc.shade_prims[prim];
+            const rt_material m = sc.materials[sh.material];
+            const Surface s = compute_surface(sc, sh, m.side, o, d, np.t[idx], np.bu[idx], np.bv[idx]);
+            d3 refr_dir = mk3(0.0, 0.0, 0.0);
             bool cast_shadows = false;
             if (m.kind == RT_MAT_PHONG) {
+                phong_flag = 0x80000000u;  // its one reflection child is the mirror direction itself
                 nR = m.reflectivity > 0.0 ? 1u : 0u;
                 if (!illum) {
                     nG = gi_rays(sc, level);
@@ -515,56 +590,126 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
                     bit++;
                 }
             }
+            // ---- context for phase B
+            L.Px[tid] = s.P.x;
+            L.Py[tid] = s.P.y;
+            L.Pz[tid] = s.P.z;
+            L.nx[tid] = s.n.x;
+            L.ny[tid] = s.n.y;
+            L.nz[tid] = s.n.z;
+            if (nR) {
+                const d3 rdir = reflect_dir(d, s.n);
+                L.rx[tid] = rdir.x;
+                L.ry[tid] = rdir.y;
+                L.rz[tid] = rdir.z;
+                L.max_angle[tid] = HALF_PI_D * m.roughness;
+            }
+            if (nT) {
+                L.tx[tid] = refr_dir.x;
+                L.ty[tid] = refr_dir.y;
+                L.tz[tid] = refr_dir.z;
+            }
+            if (nR + nT + nG) {
+                const uint32_t root = np.root[idx];
+                uint32_t px, py, sample;
+                item_to_pixel(wl, root, &px, &py, &sample);
+                L.root[tid] = root;
+                L.pixel[tid] = py * sc.opts.width + px;
+                L.sample[tid] = sample;
+                L.path[tid] = np.path[idx];
+                const uint32_t same_kind = child_depth | (illum ? META_ILLUM : 0u);
+                L.meta_same[tid] = same_kind;
+                L.meta_refr[tid] = same_kind | META_REFR | (sh.material << META_MAT_SHIFT);
+            }
         }
         const uint32_t total = nR + nT + nG;
+        L.counts[tid] = nR | (nT << 16) | (nG << 17) | phong_flag;
+        L.mask[tid] = mask;
         uint32_t wave_nodes, wave_shadows;
         const uint64_t child64 = wave_alloc(&ctr->node_alloc, total, &wave_nodes);
         const uint64_t shadow64 = wave_alloc(&ctr->shadow_alloc, nS, &wave_shadows);
-        // wave-uniform overflow test (first lane's base + wave total)
-        const uint64_t node_base = __shfl(child64, 0, 64), shadow_base = __shfl(shadow64, 0, 64);
-        const uint32_t first_child = static_cast<uint32_t>(child64), first_shadow = static_cast<uint32_t>(shadow64);
-        if (node_base + wave_nodes > np.capacity || shadow_base + wave_shadows > sp.capacity) {
-            if ((threadIdx.x & 63u) == 0) atomicOr(&ctr->overflow, 1u);
+        // shard-local positions; wave-uniform overflow test (first lane's base + wave total)
+        const uint64_t node_local = __shfl(child64, 0, 64), shadow_local = __shfl(shadow64, 0, 64);
+        if (node_local + wave_nodes > shards.node_cap || shadow_local + wave_shadows > shards.shadow_cap) {
+            if (lane == 0) atomicOr(&ctr->overflow, 1u);
             continue;
         }
-        if (!valid) continue;
-        np.first_child[idx] = first_child;
-        np.first_shadow[idx] = first_shadow;
-        np.counts[idx] = nR | (nT << 16) | (nG << 17);
-        np.light_mask[idx] = mask;
-        if (prim == RT_NO_HIT) continue;
-
-        // shadow rays: from the light towards the surface (raytracing_scene.rs:217-225, :429-437)
-        if (nS) {
-            uint32_t bit = 0, k = first_shadow;
-            for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                const DLight &l = sc.lights[li];
-                if (l.kind != RT_LIGHT_POINT) continue;
-                if (mask & (1u << bit)) {
-                    d3 ld = mk3(l.position[0], l.position[1], l.position[2]) - s.P;
-                    double dist = length3(ld);
-                    ld = unit3(ld);
-                    sp.dx[k] = -ld.x;
-                    sp.dy[k] = -ld.y;
-                    sp.dz[k] = -ld.z;
-                    sp.tmax[k] = dist - BIAS;  // shadow_cast(.., max_distance - BIAS), :94-96
-                    sp.light[k] = static_cast<uint8_t>(li);
-                    k++;
-                }
-                bit++;
-            }
+        const uint32_t node_base = c.node_off + static_cast<uint32_t>(node_local);
+        const uint32_t shadow_base = c.shadow_off + static_cast<uint32_t>(shadow_local);
+        const uint32_t first_child = c.node_off + static_cast<uint32_t>(child64);
+        const uint32_t first_shadow = c.shadow_off + static_cast<uint32_t>(shadow64);
+        L.incl_nodes[tid] = first_child - node_base + total;
+        L.incl_shadows[tid] = first_shadow - shadow_base + nS;
+        if (valid) {
+            np.first_child[idx] = first_child;
+            np.first_shadow[idx] = first_shadow;
+            np.counts[idx] = nR | (nT << 16) | (nG << 17);
+            np.light_mask[idx] = mask;
         }
-        if (total == 0) continue;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // phase A's LDS stores -> phase B's reads (same wave)
 
-        const uint32_t root = np.root[idx];
-        const uint64_t path = np.path[idx];
-        uint32_t px, py, sample;
-        item_to_pixel(wl, root, &px, &py, &sample);
-        const uint32_t pixel = py * sc.opts.width + px;
-        const uint32_t child_depth = level + 1;
-        uint32_t c = first_child;
-        auto emit = [&](uint32_t at, d3 dir, uint64_t cpath, uint32_t cmeta) {
-            d3 org = s.P + dir * BIAS;
+        // ---- phase B: shadow rays, from the light towards the surface (:217-225, :429-437)
+        for (uint32_t j = lane; j < wave_shadows; j += 64u) {
+            const uint32_t p = wbase + wave_owner(L.incl_shadows + wbase, j);
+            const uint32_t pm = L.mask[p];
+            uint32_t slot = j - (L.incl_shadows[p] - static_cast<uint32_t>(__popc(pm)));
+            // slot-th set bit of the parent's light mask -> index among point lights
+            uint32_t mm = pm;
+            for (uint32_t k = 0; k < slot; ++k) mm &= mm - 1u;
+            const uint32_t want = static_cast<uint32_t>(__ffs(mm)) - 1u;
+            uint32_t li = 0, seen = 0;
+            for (; li < sc.n_lights; ++li) {
+                if (sc.lights[li].kind != RT_LIGHT_POINT) continue;
+                if (seen == want) break;
+                seen++;
+            }
+            const DLight &l = sc.lights[li];
+            d3 ld = mk3(l.position[0], l.position[1], l.position[2]) - mk3(L.Px[p], L.Py[p], L.Pz[p]);
+            const double dist = length3(ld);
+            ld = unit3(ld);
+            const uint32_t k = shadow_base + j;
+            sp.dx[k] = -ld.x;
+            sp.dy[k] = -ld.y;
+            sp.dz[k] = -ld.z;
+            sp.tmax[k] = dist - BIAS;  // shadow_cast(.., max_distance - BIAS), :94-96
+            sp.light[k] = static_cast<uint8_t>(li);
+        }
+        // ---- phase B: child rays
+        for (uint32_t j = lane; j < wave_nodes; j += 64u) {
+            const uint32_t p = wbase + wave_owner(L.incl_nodes + wbase, j);
+            const uint32_t cnt = L.counts[p];
+            const uint32_t pR = cnt & 0xFFFFu, pT = (cnt >> 16) & 1u, pG = (cnt >> 17) & 0x3FFFu;
+            const uint32_t slot = j - (L.incl_nodes[p] - (pR + pT + pG));
+            const uint64_t path = L.path[p];
+            const d3 P = mk3(L.Px[p], L.Py[p], L.Pz[p]);
+            d3 dir;
+            uint64_t cpath;
+            uint32_t cmeta;
+            if (slot < pR) {
+                const d3 rdir = mk3(L.rx[p], L.ry[p], L.rz[p]);
+                cpath = path_child(path, slot);
+                cmeta = L.meta_same[p];
+                if (cnt & 0x80000000u) {  // phong mirror: no sampling
+                    dir = rdir;
+                } else {
+                    double u1, u2;
+                    rng_pair(wl.seed, L.pixel[p], L.sample[p], cpath, &u1, &u2);
+                    dir = sample_cone(rdir, L.max_angle[p], u1, u2);
+                }
+            } else if (slot < pR + pT) {
+                dir = mk3(L.tx[p], L.ty[p], L.tz[p]);
+                cpath = path_child(path, SLOT_REFRACTION);
+                cmeta = L.meta_refr[p];
+            } else {
+                const uint32_t g = slot - pR - pT;
+                cpath = path_child(path, SLOT_GI + g);
+                double u1, u2;
+                rng_pair(wl.seed, L.pixel[p], L.sample[p], cpath, &u1, &u2);
+                dir = sample_cosine_hemisphere(mk3(L.nx[p], L.ny[p], L.nz[p]), u1, u2);
+                cmeta = child_depth | META_ILLUM;
+            }
+            const d3 org = P + dir * BIAS;
+            const uint32_t at = node_base + j;
             np.ox[at] = org.x;
             np.oy[at] = org.y;
             np.oz[at] = org.z;
@@ -572,43 +717,24 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
             np.dy[at] = dir.y;
             np.dz[at] = dir.z;
             np.path[at] = cpath;
-            np.root[at] = root;
+            np.root[at] = L.root[p];
             np.meta[at] = cmeta;
-        };
-        const uint32_t same_kind = child_depth | (illum ? META_ILLUM : 0u);
-        if (nR) {
-            d3 rdir = reflect_dir(d, s.n);
-            if (m.kind == RT_MAT_PHONG) {
-                emit(c++, rdir, path_child(path, 0u), same_kind);
-            } else {
-                const double max_angle = HALF_PI_D * m.roughness;
-                for (uint32_t r = 0; r < nR; ++r) {
-                    uint64_t cp = path_child(path, r);
-                    double u1, u2;
-                    rng_pair(wl.seed, pixel, sample, cp, &u1, &u2);
-                    emit(c++, sample_cone(rdir, max_angle, u1, u2), cp, same_kind);
-                }
-            }
         }
-        if (nT) emit(c++, refr_dir, path_child(path, SLOT_REFRACTION), same_kind | META_REFR | (sh.material << META_MAT_SHIFT));
-        for (uint32_t g = 0; g < nG; ++g) {
-            uint64_t cp = path_child(path, SLOT_GI + g);
-            double u1, u2;
-            rng_pair(wl.seed, pixel, sample, cp, &u1, &u2);
-            emit(c++, sample_cosine_hemisphere(s.n, u1, u2), cp, child_depth | META_ILLUM);
-        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // phase B's reads before the next round's stores
     }
 }
 
 // ------------------------------------------------------------------ resolve
 // Bottom-up shading of every node of `level`; children of level+1 are resolved.
 // Result: (t,bu,bv) <- RGB, prim <- flag (illumination nodes: occluded).
-__global__ __launch_bounds__(BLOCK) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctr,
+__global__ __launch_bounds__(BLOCK) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
                                                   uint32_t level) {
+    const ShardCtx c = shard_ctx(ctrs, shards);
+    Counters *ctr = c.ctr;
     if (ctr->overflow) return;
-    const uint32_t start = ctr->level_start[level], count = ctr->level_count[level];
+    const uint32_t start = c.node_off + ctr->level_start[level], count = ctr->level_count[level];
     const bool next_real = level + 1 < sc.opts.max_depth;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+    for (uint32_t i = c.bid * BLOCK + threadIdx.x; i < count; i += c.nblocks * BLOCK) {
         const uint32_t idx = start + i;
         const uint32_t meta = np.meta[idx];
         const uint32_t prim = (meta & META_INACTIVE) ? RT_NO_HIT : np.prim[idx];
@@ -786,15 +912,17 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(SceneDev sc, NodePool np, Sha
 
 // ------------------------------------------------------------------ accumulate / tonemap / AOVs
 // screen_raycast :605-612: sum of the per-sample clamped colours, in sample order.
-__global__ __launch_bounds__(BLOCK) void k_accumulate(SceneDev sc, WorkList wl, NodePool np, Counters *ctr,
-                                                     uint32_t item0, uint32_t n_items, double *accum) {
-    if (ctr->overflow) return;
-    const uint32_t n_pix = n_items / wl.ns;
-    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < n_pix; p += gridDim.x * BLOCK) {
-        const uint32_t node0 = p * wl.ns;
+__global__ __launch_bounds__(BLOCK) void k_accumulate(SceneDev sc, WorkList wl, NodePool np, Counters *ctrs, Shards shards,
+                                                     double *accum) {
+    for (uint32_t k = 0; k < shards.count; ++k)  // += semantics: nothing may land if the batch is going to be re-run
+        if (ctrs[k].overflow) return;
+    const ShardCtx c = shard_ctx(ctrs, shards);
+    const uint32_t n_pix = c.ctr->level_count[0] / wl.ns;
+    for (uint32_t p = c.bid * BLOCK + threadIdx.x; p < n_pix; p += c.nblocks * BLOCK) {
+        const uint32_t node0 = c.node_off + p * wl.ns;
         if (np.meta[node0] & META_INACTIVE) continue;
         uint32_t px, py, sample;
-        item_to_pixel(wl, item0 + node0, &px, &py, &sample);
+        item_to_pixel(wl, np.root[node0], &px, &py, &sample);
         d3 sum = mk3(np.t[node0], np.bu[node0], np.bv[node0]);
         for (uint32_t s = 1; s < wl.ns; ++s) sum = sum + mk3(np.t[node0 + s], np.bu[node0 + s], np.bv[node0 + s]);
         const uint64_t at = (static_cast<uint64_t>(py) * sc.opts.width + px) * 3ull;
@@ -827,13 +955,12 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(uint32_t n_pixels, uint32_t s
 }
 
 // primary-hit AOVs of level-0 nodes (one sample per pixel): id, t, shading normal
-__global__ __launch_bounds__(BLOCK) void k_primary_aov(SceneDev sc, WorkList wl, NodePool np, uint32_t item0,
-                                                      uint32_t n_items, uint32_t *out_id, double *out_t,
-                                                      double *out_n) {
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_items; i += gridDim.x * BLOCK) {
+__global__ __launch_bounds__(BLOCK) void k_primary_aov(SceneDev sc, WorkList wl, NodePool np, uint32_t n_items,
+                                                      uint32_t *out_id, double *out_t, double *out_n) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_items; i += gridDim.x * BLOCK) {  // single-shard launches only
         if (np.meta[i] & META_INACTIVE) continue;
         uint32_t px, py, sample;
-        item_to_pixel(wl, item0 + i, &px, &py, &sample);
+        item_to_pixel(wl, np.root[i], &px, &py, &sample);
         const uint64_t at = static_cast<uint64_t>(py) * sc.opts.width + px;
         const uint32_t prim = np.prim[i];
         out_id[at] = prim;
