@@ -348,6 +348,9 @@ Shards plan_shards(const rt_scene *s, uint64_t n, uint32_t ns) {
     return sh;
 }
 
+// dynamic LDS of the traversal kernels: per-lane stack of (max leaf depth + 2) entries (sentinel included)
+uint32_t stack_lds_bytes(const rt_scene *s) { return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t); }
+
 Shards single_shard(const rt_scene *s) { return Shards{1u, s->np.capacity, s->sp.capacity, 1u}; }
 
 }  // namespace
@@ -624,8 +627,8 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
             for (uint32_t level = 0; level < max_depth; ++level) {
                 const uint32_t g = level == 0 ? shard_grid(s, sh, n, 4) : g_level;
                 timer.begin(CLS_CLOSEST);
-                if (count_work) hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(BLOCK), 0, stream, s->dev, np, s->d_ctr, sh, level);
-                else hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(BLOCK), 0, stream, s->dev, np, s->d_ctr, sh, level);
+                if (count_work) hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level);
+                else hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level);
                 timer.end();
                 timer.begin(CLS_EXPAND);
                 hipLaunchKernelGGL(k_expand, dim3(level == 0 ? shard_grid(s, sh, n, 8) : g_wide), dim3(BLOCK), 0, stream, s->dev, wl, np,
@@ -635,9 +638,9 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
             }
             timer.begin(CLS_SHADOW);
             if (count_work)
-                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(g_level), dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, 0u);
+                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, s->d_ctr, sh, 0u);
             else
-                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(g_level), dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, 0u);
+                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, s->d_ctr, sh, 0u);
             timer.end();
             for (uint32_t level = max_depth; level-- > 0;) {
                 timer.begin(CLS_RESOLVE);
@@ -794,7 +797,7 @@ int rt_query_primary(rt_scene *s, uint32_t *prim_id, double *t, double *normal3)
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, one, n);
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, s->d_ctr, one,
                            static_cast<uint32_t>(item0), n);
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, n, 4)), dim3(BLOCK), 0, nullptr, s->dev, s->np, s->d_ctr, one,
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, n, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, s->np, s->d_ctr, one,
                            0u);
         hipLaunchKernelGGL(k_primary_aov, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, n, d_id, d_t,
                            d_n);
@@ -839,10 +842,10 @@ int rt_trace_rays(rt_scene *s, uint32_t n, const double *origin, const double *d
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, one, m);
         if (shadow) {
             HIP_TRY(hipMemcpy(np.t, tmax + done, m * sizeof(double), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid_for(s, m, 4)), dim3(BLOCK), 0, nullptr, s->dev, np, s->sp,
+            hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, s->sp,
                                s->d_ctr, one, m);
         } else {
-            hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, m, 4)), dim3(BLOCK), 0, nullptr, s->dev, np, s->d_ctr, one,
+            hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, s->d_ctr, one,
                                0u);
         }
         HIP_TRY(hipDeviceSynchronize());

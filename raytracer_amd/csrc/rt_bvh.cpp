@@ -13,7 +13,20 @@ namespace {
 
 constexpr int kBins = 16;
 constexpr double kIntersectCost = 3.0;  // one primitive test ~ three node visits (f64, 9 divisions)
-constexpr uint32_t kLeafTarget = 4;
+constexpr uint32_t kLeafTarget = 1;  // one primitive per leaf: the parent's child box IS that primitive's own AABB,
+                                     // so the node test doubles as the leaf's pre-filter
+
+// f64 -> f32 towards -inf / +inf (node boxes must contain the exact boxes)
+float round_down(double x) {
+    float f = static_cast<float>(x);
+    if (static_cast<double>(f) > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+float round_up(double x) {
+    float f = static_cast<float>(x);
+    if (static_cast<double>(f) < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
 
 struct Builder {
     const std::vector<Aabb> &boxes;
@@ -70,7 +83,7 @@ struct Builder {
         uint32_t mid = 0;
         bool split_found = false;
 
-        if (count <= 2 || (count <= MAX_LEAF_PRIMS && depth_budget == 0)) {
+        if (count <= kLeafTarget || (count <= MAX_LEAF_PRIMS && depth_budget == 0)) {
             out.n_leaves++;
             return make_leaf_ref(first, count);
         }
@@ -163,10 +176,10 @@ struct Builder {
         uint32_t r = build(mid, first + count - mid, depth + 1, &rb);
         BvhNode &n = out.nodes[self];
         for (int k = 0; k < 3; ++k) {
-            n.lmin[k] = lb.mn[k];
-            n.lmax[k] = lb.mx[k];
-            n.rmin[k] = rb.mn[k];
-            n.rmax[k] = rb.mx[k];
+            n.lmin[k] = round_down(lb.mn[k]);
+            n.lmax[k] = round_up(lb.mx[k]);
+            n.rmin[k] = round_down(rb.mn[k]);
+            n.rmax[k] = round_up(rb.mx[k]);
         }
         n.left = l;
         n.right = r;

@@ -322,42 +322,61 @@ __device__ __forceinline__ bool hit_triangle(const double *__restrict__ g, uint3
 }
 
 // ------------------------------------------------------------------ BVH node culling
-// Conservative slab test: never rejects a box containing a primitive whose own
-// exact predicate passes.  Per ray: inv = 1/d, o_lo = o + P, o_hi = o - P with
-// P = 2^-47 * (|o|_inf + scene scale), i.e. 64 ulps of the coordinates (absorbs the rounding of this test AND of
-// the primitives' reference-order AABB arithmetic).  NaNs (0 * inf) drop out of
-// fmin/fmax, which keeps the slab -> conservative.
+// Conservative slab test in f32: never rejects a box that contains a primitive
+// whose exact f64 predicate passes within the t limit.
+//   * node boxes are the exact f64 unions rounded outward to f32 (rt_bvh.cpp);
+//   * the ray origin is rounded to f32 (error <= 2^-24 |o|), the subtraction
+//     b - o rounds once more (<= 2^-24 (|b| + |o|)); both, and the rounding of
+//     the primitives' reference-order AABB arithmetic in f64, are absorbed by
+//     widening every slab by P = 2^-20 (|o|_inf + scene scale) on each side;
+//   * inv = 1/d and the product carry a relative error <= 2^-23: entry
+//     distances are lowered and exit distances raised by 2^-21 relative;
+//   * NaNs (0 * inf) drop out of fminf/fmaxf, which keeps the slab;
+//     comparisons are written so that a NaN keeps the node.
 struct CullRay {
-    d3 o_lo, o_hi, inv;
+    float ox, oy, oz;
+    float ix, iy, iz;
+    float P;
 };
 
 __device__ __forceinline__ CullRay make_cull_ray(const RayD &r, double scene_scale) {
-    double m = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
-    double P = 0x1.0p-47 * (m + scene_scale);
+    const double m = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
     CullRay c;
-    c.o_lo = mk3(r.o.x + P, r.o.y + P, r.o.z + P);
-    c.o_hi = mk3(r.o.x - P, r.o.y - P, r.o.z - P);
-    c.inv = mk3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    c.P = static_cast<float>(0x1.0p-20 * (m + scene_scale));
+    c.ox = static_cast<float>(r.o.x);
+    c.oy = static_cast<float>(r.o.y);
+    c.oz = static_cast<float>(r.o.z);
+    c.ix = static_cast<float>(1.0 / r.d.x);
+    c.iy = static_cast<float>(1.0 / r.d.y);
+    c.iz = static_cast<float>(1.0 / r.d.z);
     return c;
 }
 
-// returns entry distance (lower bound) or +inf-like miss via `hit`
-__device__ __forceinline__ bool box_cull_test(const double *__restrict__ bmin, const double *__restrict__ bmax,
-                                              const CullRay &c, double t_limit, double *t_entry) {
-    double t1 = (bmin[0] - c.o_lo.x) * c.inv.x, t2 = (bmax[0] - c.o_hi.x) * c.inv.x;
-    double tn = fmin(t1, t2), tf = fmax(t1, t2);
-    t1 = (bmin[1] - c.o_lo.y) * c.inv.y;
-    t2 = (bmax[1] - c.o_hi.y) * c.inv.y;
-    tn = fmax(tn, fmin(t1, t2));
-    tf = fmin(tf, fmax(t1, t2));
-    t1 = (bmin[2] - c.o_lo.z) * c.inv.z;
-    t2 = (bmax[2] - c.o_hi.z) * c.inv.z;
-    tn = fmax(tn, fmin(t1, t2));
-    tf = fmin(tf, fmax(t1, t2));
+// t limit of a traversal in f32, rounded up with slack
+__device__ __forceinline__ float cull_limit_f32(double t_limit) {
+    const float f = static_cast<float>(t_limit);
+    return f + fabsf(f) * 0x1.0p-21f;  // inf stays inf
+}
+
+// `bmin`/`bmax`: 3 floats each.  Returns false when the box can be skipped;
+// *t_entry is the (lowered) entry distance, used to order the children.
+__device__ __forceinline__ bool box_cull_test(const float *__restrict__ bmin, const float *__restrict__ bmax, const CullRay &c,
+                                              float t_limit, float *t_entry) {
+    float t1 = ((bmin[0] - c.ox) - c.P) * c.ix, t2 = ((bmax[0] - c.ox) + c.P) * c.ix;
+    float tn = fminf(t1, t2), tf = fmaxf(t1, t2);
+    t1 = ((bmin[1] - c.oy) - c.P) * c.iy;
+    t2 = ((bmax[1] - c.oy) + c.P) * c.iy;
+    tn = fmaxf(tn, fminf(t1, t2));
+    tf = fminf(tf, fmaxf(t1, t2));
+    t1 = ((bmin[2] - c.oz) - c.P) * c.iz;
+    t2 = ((bmax[2] - c.oz) + c.P) * c.iz;
+    tn = fmaxf(tn, fminf(t1, t2));
+    tf = fminf(tf, fmaxf(t1, t2));
+    tn = fminf(tn * (1.0f - 0x1.0p-21f), tn * (1.0f + 0x1.0p-21f));  // lowered; +-inf stay +-inf
+    tf = fmaxf(tf * (1.0f - 0x1.0p-21f), tf * (1.0f + 0x1.0p-21f));  // raised
     *t_entry = tn;
-    // written so that any NaN keeps the node (comparisons false -> not culled)
     if (tn > tf) return false;
-    if (tf < 0.0) return false;
+    if (tf < 0.0f) return false;
     if (tn > t_limit) return false;
     return true;
 }

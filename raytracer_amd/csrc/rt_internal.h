@@ -26,15 +26,17 @@ constexpr uint32_t LEAF_FLAG = 0x80000000u;
 constexpr uint32_t SLOT_REFRACTION = 0x40000000u;
 constexpr uint32_t SLOT_GI = 0x80000000u;
 
-// BVH2 node: boxes of both children, child references.
+// BVH2 node: boxes of both children in f32, rounded OUTWARD from the exact f64
+// unions of the primitives' world AABBs, + child references.  Node boxes only
+// cull (conservatively); every hit decision is taken in f64 at the leaves.
 // ref: bit31 set -> leaf, bits 28..30 = count-1, bits 0..27 = first leaf record.
 struct alignas(16) BvhNode {
-    double lmin[3], lmax[3];
-    double rmin[3], rmax[3];
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
     uint32_t left, right;
-    uint32_t _pad[6];
+    uint32_t _pad[2];
 };
-static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
 // Leaf primitive record (bounded primitives only), BVH-leaf order.
 //   meta: bits 0..1 type, bits 2..3 side, bits 4..31 transform index

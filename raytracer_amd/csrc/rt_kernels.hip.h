@@ -274,6 +274,27 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev sc, WorkList wl, Node
 }
 
 // ------------------------------------------------------------------ traversal
+// One ray per lane.  Per-lane short stack in LDS, `stack_depth` entries of
+// BLOCK words each (entry e of thread t at stack[e * BLOCK + t]: conflict-free);
+// the host sizes it from the BVH (max leaf depth + 2), so small scenes keep
+// LDS use low and occupancy high.  Entry 0 holds a sentinel.
+//
+// "while-while" form: every lane first descends through interior nodes until it
+// holds a leaf (or is done), then the wave tests leaves together -- a diverged
+// wave does not pay for the node path and the leaf path in every iteration.
+//
+// Leaf primitive = BoundedObject::intersect (bounds.rs:172-181): the primitive's
+// own world-AABB slab test AND the object-space primitive test.  Both are pure
+// predicates, so they are evaluated cheapest-first: the builder makes
+// single-primitive leaves, whose box in the parent node IS the primitive's own
+// AABB, so the conservative node test has already pre-filtered it (no divisions,
+// running t limit applied); then the primitive test, and only for primitive
+// hits the reference-order AABB arithmetic (6 divisions).
+#ifndef TRACE_WAVES
+#define TRACE_WAVES 4
+#endif
+constexpr uint32_t STACK_SENTINEL = 0x7FFFFFFFu;  // not a leaf ref, not a node index
+
 struct ObjRayCache {
     uint32_t xf;
     RayD r;
@@ -281,9 +302,7 @@ struct ObjRayCache {
 
 template <bool SHADOW>
 __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPrim *__restrict__ lp, const RayD &ray,
-                                               ObjRayCache &cache, bool has_max, double max_distance, HitRec *h) {
-    // BoundedObject::intersect (bounds.rs:172-181): own AABB first, then object space
-    if (!prim_box_test(lp->bmin, lp->bmax, ray, has_max, max_distance)) return false;
+                                               ObjRayCache &cache, double max_distance, HitRec *h) {
     const uint32_t meta = lp->meta;
     const uint32_t xf = meta >> 4;
     if (xf != cache.xf) {  // Ray::transform (ray_intersection.rs:33-43), shared by a mesh's faces
@@ -293,19 +312,49 @@ __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPri
         cache.xf = xf;
     }
     const uint32_t type = meta & 3u, side = (meta >> 2) & 3u;
-    if (type == RT_PRIM_TRIANGLE) return hit_triangle(lp->geom, side, SHADOW, cache.r, has_max, max_distance, h);
-    if (type == RT_PRIM_SPHERE) return hit_sphere(lp->geom[0], side, SHADOW, cache.r, has_max, max_distance, h);
-    return hit_cube(lp->geom[0], side, SHADOW, cache.r, has_max, max_distance, h);
+    bool hit;
+    if (type == RT_PRIM_TRIANGLE) hit = hit_triangle(lp->geom, side, SHADOW, cache.r, SHADOW, max_distance, h);
+    else if (type == RT_PRIM_SPHERE) hit = hit_sphere(lp->geom[0], side, SHADOW, cache.r, SHADOW, max_distance, h);
+    else hit = hit_cube(lp->geom[0], side, SHADOW, cache.r, SHADOW, max_distance, h);
+    if (!hit) return false;
+    return prim_box_test(lp->bmin, lp->bmax, ray, SHADOW, max_distance);
 }
 
 __device__ __forceinline__ double cull_limit(double t) { return t + 1e-9 * (1.0 + fabs(t)); }
 
+// Descend from `cur` through interior nodes until a leaf ref or the sentinel.
+template <bool COUNT>
+__device__ __forceinline__ uint32_t descend(const SceneDev &sc, const CullRay &cr, float limit, uint32_t cur, uint32_t *stack,
+                                            uint32_t &sp, unsigned long long &n_nodes) {
+    while (!(cur & LEAF_FLAG) && cur != STACK_SENTINEL) {
+        const BvhNode *nd = sc.nodes + cur;
+        if (COUNT) n_nodes++;
+        float tl, tr;
+        const bool hl = box_cull_test(nd->lmin, nd->lmax, cr, limit, &tl);
+        const bool hr = box_cull_test(nd->rmin, nd->rmax, cr, limit, &tr);
+        const uint32_t lref = nd->left, rref = nd->right;
+        if (hl && hr) {
+            const bool left_first = !(tr < tl);
+            stack[(sp++) * BLOCK] = left_first ? rref : lref;
+            cur = left_first ? lref : rref;
+        } else if (hl) {
+            cur = lref;
+        } else if (hr) {
+            cur = rref;
+        } else {
+            cur = stack[(--sp) * BLOCK];
+        }
+    }
+    return cur;
+}
+
 // KdTreeAccelerator::raycast semantics, traversal-order independent form
 // (DESIGN.md "canonical hit"): minimum of (t, bounded?, primitive id).
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, NodePool np, Counters *ctrs, Shards shards,
+__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev sc, NodePool np, Counters *ctrs, Shards shards,
                                                         uint32_t level) {
-    __shared__ uint32_t stack[STACK_DEPTH * BLOCK];
+    extern __shared__ uint32_t stack_lds[];
+    uint32_t *stack = stack_lds + threadIdx.x;
     const ShardCtx c = shard_ctx(ctrs, shards);
     Counters *ctr = c.ctr;
     if (ctr->overflow) return;
@@ -345,51 +394,30 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, NodePool n
             const CullRay cr = make_cull_ray(ray, sc.scene_scale);
             ObjRayCache cache;
             cache.xf = 0xFFFFFFFFu;
-            uint32_t sp = 0;
+            stack[0] = STACK_SENTINEL;
+            uint32_t sp = 1;
             uint32_t cur = sc.root_ref;
             while (true) {
-                if (cur & LEAF_FLAG) {
-                    const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
-                    for (uint32_t k = 0; k < n; ++k) {
-                        const LeafPrim *lp = sc.leaf_prims + first + k;
-                        HitRec h;
-                        if (COUNT) n_prims++;
-                        if (test_leaf_prim<false>(sc, lp, ray, cache, false, 0.0, &h)) {
-                            const uint32_t pid = lp->prim_id;
-                            bool better = best_id == RT_NO_HIT || h.t < best_t ||
-                                          (h.t == best_t && best_bounded && pid < best_id);
-                            if (better) {
-                                best_t = h.t;
-                                best_id = pid;
-                                best_bu = h.bu;
-                                best_bv = h.bv;
-                                best_bounded = true;
-                            }
+                cur = descend<COUNT>(sc, cr, cull_limit_f32(cull_limit(best_t)), cur, stack, sp, n_nodes);
+                if (cur == STACK_SENTINEL) break;
+                const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
+                for (uint32_t k = 0; k < n; ++k) {
+                    const LeafPrim *lp = sc.leaf_prims + first + k;
+                    HitRec h;
+                    if (COUNT) n_prims++;
+                    if (test_leaf_prim<false>(sc, lp, ray, cache, 0.0, &h)) {
+                        const uint32_t pid = lp->prim_id;
+                        bool better = best_id == RT_NO_HIT || h.t < best_t || (h.t == best_t && best_bounded && pid < best_id);
+                        if (better) {
+                            best_t = h.t;
+                            best_id = pid;
+                            best_bu = h.bu;
+                            best_bv = h.bv;
+                            best_bounded = true;
                         }
                     }
-                    if (sp == 0) break;
-                    cur = stack[(--sp) * BLOCK + threadIdx.x];
-                } else {
-                    const BvhNode *nd = sc.nodes + cur;
-                    if (COUNT) n_nodes++;
-                    const double limit = cull_limit(best_t);
-                    double tl, tr;
-                    const bool hl = box_cull_test(nd->lmin, nd->lmax, cr, limit, &tl);
-                    const bool hr = box_cull_test(nd->rmin, nd->rmax, cr, limit, &tr);
-                    const uint32_t lref = nd->left, rref = nd->right;
-                    if (hl && hr) {
-                        const bool left_first = !(tr < tl);
-                        stack[(sp++) * BLOCK + threadIdx.x] = left_first ? rref : lref;
-                        cur = left_first ? lref : rref;
-                    } else if (hl) {
-                        cur = lref;
-                    } else if (hr) {
-                        cur = rref;
-                    } else {
-                        if (sp == 0) break;
-                        cur = stack[(--sp) * BLOCK + threadIdx.x];
-                    }
                 }
+                cur = stack[(--sp) * BLOCK];
             }
         }
         np.prim[idx] = best_id;
@@ -406,9 +434,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, NodePool n
 // KdTreeAccelerator::shadow_cast semantics: OR over primitives within max_distance.
 // PROBE: rays come from the node pool (rt_trace_rays) instead of the shadow pool.
 template <bool COUNT, bool PROBE>
-__global__ __launch_bounds__(BLOCK) void k_trace_shadow(SceneDev sc, NodePool np, ShadowPool sp_pool, Counters *ctrs,
+__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc, NodePool np, ShadowPool sp_pool, Counters *ctrs,
                                                        Shards shards, uint32_t probe_count) {
-    __shared__ uint32_t stack[STACK_DEPTH * BLOCK];
+    extern __shared__ uint32_t stack_lds[];
+    uint32_t *stack = stack_lds + threadIdx.x;
     const ShardCtx c = shard_ctx(ctrs, shards);
     Counters *ctr = c.ctr;
     if (ctr->overflow) return;
@@ -444,42 +473,23 @@ __global__ __launch_bounds__(BLOCK) void k_trace_shadow(SceneDev sc, NodePool np
         }
         if (!occluded && sc.root_ref != 0xFFFFFFFFu) {
             const CullRay cr = make_cull_ray(ray, sc.scene_scale);
-            const double limit = cull_limit(tmax);
+            const float limit = cull_limit_f32(cull_limit(tmax));
             ObjRayCache cache;
             cache.xf = 0xFFFFFFFFu;
-            uint32_t sp = 0;
+            stack[0] = STACK_SENTINEL;
+            uint32_t sp = 1;
             uint32_t cur = sc.root_ref;
             while (true) {
-                if (cur & LEAF_FLAG) {
-                    const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
-                    for (uint32_t k = 0; k < n && !occluded; ++k) {
-                        HitRec h;
-                        if (COUNT) n_prims++;
-                        if (test_leaf_prim<true>(sc, sc.leaf_prims + first + k, ray, cache, true, tmax, &h))
-                            occluded = true;
-                    }
-                    if (occluded || sp == 0) break;
-                    cur = stack[(--sp) * BLOCK + threadIdx.x];
-                } else {
-                    const BvhNode *nd = sc.nodes + cur;
-                    if (COUNT) n_nodes++;
-                    double tl, tr;
-                    const bool hl = box_cull_test(nd->lmin, nd->lmax, cr, limit, &tl);
-                    const bool hr = box_cull_test(nd->rmin, nd->rmax, cr, limit, &tr);
-                    const uint32_t lref = nd->left, rref = nd->right;
-                    if (hl && hr) {
-                        const bool left_first = !(tr < tl);
-                        stack[(sp++) * BLOCK + threadIdx.x] = left_first ? rref : lref;
-                        cur = left_first ? lref : rref;
-                    } else if (hl) {
-                        cur = lref;
-                    } else if (hr) {
-                        cur = rref;
-                    } else {
-                        if (sp == 0) break;
-                        cur = stack[(--sp) * BLOCK + threadIdx.x];
-                    }
+                cur = descend<COUNT>(sc, cr, limit, cur, stack, sp, n_nodes);
+                if (cur == STACK_SENTINEL) break;
+                const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
+                for (uint32_t k = 0; k < n && !occluded; ++k) {
+                    HitRec h;
+                    if (COUNT) n_prims++;
+                    if (test_leaf_prim<true>(sc, sc.leaf_prims + first + k, ray, cache, tmax, &h)) occluded = true;
                 }
+                if (occluded) break;
+                cur = stack[(--sp) * BLOCK];
             }
         }
         if (PROBE) np.prim[i] = occluded ? 1u : 0u;

@@ -23,7 +23,8 @@ class DeviceError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmi355rt.so")
+    # MI355RT_LIB: load another build of the same library (kernel tuning experiments)
+    return os.environ.get("MI355RT_LIB") or os.path.join(_HERE, "libmi355rt.so")
 
 
 def lib():
