@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -521,7 +522,17 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     if ((rc = upload(bvh.nodes, &dev.nodes, sc->allocs, bytes))) return rc;
     if ((rc = upload(leaf, &dev.leaf_prims, sc->allocs, bytes))) return rc;
     if ((rc = upload(planes, &dev.planes, sc->allocs, bytes))) return rc;
+    // get_emissive_phong (:135-167) adds a child only if reflectivity > 0; get_emissive_physical (:263-337)
+    // only if max_reflected_rays > 0 or opacity < 1: otherwise an illumination ray's result is the emissive colour
+    std::vector<uint32_t> prim_flags(d->n_prims);
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const rt_material &m = d->materials[shade[i].material];
+        const bool terminal = m.kind == RT_MAT_PHONG ? !(m.reflectivity > 0.0) : (o.max_reflected_rays == 0 && !(m.opacity < 1.0));
+        const bool emissive = m.emissive[0] != 0.0 || m.emissive[1] != 0.0 || m.emissive[2] != 0.0;
+        prim_flags[i] = (terminal ? PRIM_ILLUM_TERMINAL : 0u) | (emissive ? PRIM_EMISSIVE : 0u);
+    }
     if ((rc = upload(shade, &dev.shade_prims, sc->allocs, bytes))) return rc;
+    if ((rc = upload(prim_flags, &dev.prim_flags, sc->allocs, bytes))) return rc;
     if ((rc = upload(inv, &dev.inv_world, sc->allocs, bytes))) return rc;
     if ((rc = upload(tri_nrm, &dev.tri_nrm, sc->allocs, bytes))) return rc;
     if ((rc = upload(tri_uv, &dev.tri_uv, sc->allocs, bytes))) return rc;
@@ -627,12 +638,13 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
             for (uint32_t level = 0; level < max_depth; ++level) {
                 const uint32_t g = level == 0 ? shard_grid(s, sh, n, 4) : g_level;
                 timer.begin(CLS_CLOSEST);
-                if (count_work) hipLaunchKernelGGL(k_trace_closest<true>, dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level);
-                else hipLaunchKernelGGL(k_trace_closest<false>, dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level);
+                if (count_work) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level);
+                else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level);
                 timer.end();
                 timer.begin(CLS_EXPAND);
-                hipLaunchKernelGGL(k_expand, dim3(level == 0 ? shard_grid(s, sh, n, 8) : g_wide), dim3(BLOCK), 0, stream, s->dev, wl, np,
-                                   sp, s->d_ctr, sh, level);
+                const uint32_t ge = level == 0 ? shard_grid(s, sh, n, 8) : g_wide;
+                if (count_work) hipLaunchKernelGGL(k_expand<true>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, s->d_ctr, sh, level);
+                else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, s->d_ctr, sh, level);
                 hipLaunchKernelGGL(k_advance_level, dim3(1), dim3(64), 0, stream, s->d_ctr, sh, level);
                 timer.end();
             }
@@ -668,7 +680,13 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
             c.prims_tested_closest += ck.prims_tested_closest;
             c.nodes_visited_shadow += ck.nodes_visited_shadow;
             c.prims_tested_shadow += ck.prims_tested_shadow;
+            for (uint32_t l = 0; l < MAX_LEVELS; ++l)
+                for (uint32_t q = 0; q < 4; ++q) c.census[l][q] += ck.census[l][q];
         }
+        if (count_work && std::getenv("MI355RT_CENSUS"))
+            for (uint32_t l = 0; l < max_depth && l < MAX_LEVELS; ++l)
+                std::fprintf(stderr, "[mi355rt census] level %u: colour %llu illum %llu miss %llu no-emit %llu\n", l, c.census[l][0],
+                             c.census[l][1], c.census[l][2], c.census[l][3]);
         float cls_ms[CLS_COUNT] = {0};
         uint32_t cls_n[CLS_COUNT] = {0};
         timer.collect(cls_ms, cls_n, CLS_COUNT);
@@ -797,7 +815,7 @@ int rt_query_primary(rt_scene *s, uint32_t *prim_id, double *t, double *normal3)
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, one, n);
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, s->d_ctr, one,
                            static_cast<uint32_t>(item0), n);
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, n, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, s->np, s->d_ctr, one,
+        hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid_for(s, n, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, s->np, s->d_ctr, one,
                            0u);
         hipLaunchKernelGGL(k_primary_aov, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, n, d_id, d_t,
                            d_n);
@@ -845,7 +863,7 @@ int rt_trace_rays(rt_scene *s, uint32_t n, const double *origin, const double *d
             hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, s->sp,
                                s->d_ctr, one, m);
         } else {
-            hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, s->d_ctr, one,
+            hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, s->d_ctr, one,
                                0u);
         }
         HIP_TRY(hipDeviceSynchronize());

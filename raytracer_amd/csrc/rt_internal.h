@@ -56,6 +56,10 @@ struct alignas(16) PlanePrim {
     uint32_t meta;  // as LeafPrim::meta
 };
 
+// prim_flags bits
+constexpr uint32_t PRIM_ILLUM_TERMINAL = 1u;  // get_emissive_* of this surface = its emissive colour, no child rays
+constexpr uint32_t PRIM_EMISSIVE = 2u;        // emissive colour is not all zero
+
 // Shading-side record, primitive-ID order.
 struct alignas(16) ShadePrim {
     uint32_t type;
@@ -98,6 +102,7 @@ struct SceneDev {
     double scene_scale;   // max |coordinate| of the root box
     // shading
     const ShadePrim *shade_prims;
+    const uint32_t *prim_flags;  // primitive-ID order, PRIM_* bits
     const double *inv_world;  // [n_transforms*12]
     const double *tri_nrm;    // [n_tris*9]
     const double *tri_uv;     // [n_tris*6]
@@ -115,11 +120,14 @@ struct SceneDev {
 //   bit  4     refraction child (ray carries the parent's material ior)
 //   bit  5     inactive (padding pixel outside the render window)
 //   bit  6     probe ray of rt_trace_rays (treated as Secondary)
+//   bit  7     done: the trace kernel already wrote the node's final result (misses,
+//              illumination nodes that hit a surface with nothing to gather)
 //   bits 8..31 material of the parent hit (valid when bit 4)
 constexpr uint32_t META_DEPTH_MASK = 7u;
 constexpr uint32_t META_ILLUM = 8u;
 constexpr uint32_t META_REFR = 16u;
 constexpr uint32_t META_INACTIVE = 32u;
+constexpr uint32_t META_DONE = 128u;  // bit 7: result already final (set by k_trace_closest), nothing to expand or resolve
 constexpr uint32_t META_MAT_SHIFT = 8u;
 
 // SoA node pool.  After resolve, (t,bu,bv) hold the node's RGB result and
@@ -159,6 +167,9 @@ struct Counters {
     uint32_t active_camera;  // camera rays inside the window
     unsigned long long nodes_visited_closest, prims_tested_closest;
     unsigned long long nodes_visited_shadow, prims_tested_shadow;
+    // RT_FLAG_COUNT_WORK census per level: [0] colour nodes, [1] illumination nodes,
+    // [2] misses, [3] nodes that emit neither children nor shadow rays
+    unsigned long long census[MAX_LEVELS][4];
 };
 
 // The wavefront pools are split into `count` shards.  A shard is an independent

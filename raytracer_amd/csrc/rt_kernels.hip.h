@@ -206,6 +206,8 @@ __global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
     ctr->active_camera = 0;
     ctr->nodes_visited_closest = ctr->prims_tested_closest = 0;
     ctr->nodes_visited_shadow = ctr->prims_tested_shadow = 0;
+    for (uint32_t l = 0; l < MAX_LEVELS; ++l)
+        for (uint32_t q = 0; q < 4; ++q) ctr->census[l][q] = 0;
 }
 
 __global__ void k_advance_level(Counters *ctrs, Shards sh, uint32_t level) {
@@ -350,7 +352,14 @@ __device__ __forceinline__ uint32_t descend(const SceneDev &sc, const CullRay &c
 
 // KdTreeAccelerator::raycast semantics, traversal-order independent form
 // (DESIGN.md "canonical hit"): minimum of (t, bounded?, primitive id).
-template <bool COUNT>
+//
+// FINALIZE (render path): nodes whose result needs neither child rays nor
+// shading are finished here -- misses (zero), and get_illumination hits on a
+// surface with nothing to gather (emissive colour + occlusion flag, :492-520
+// with :135-167 / :263-337).  They get META_DONE and their (t,bu,bv,prim) hold
+// the resolved (RGB, flag); k_expand / k_resolve skip them.  On scene.json that
+// is 80 % of all nodes.
+template <bool COUNT, bool FINALIZE>
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev sc, NodePool np, Counters *ctrs, Shards shards,
                                                         uint32_t level) {
     extern __shared__ uint32_t stack_lds[];
@@ -362,7 +371,8 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
     unsigned long long n_nodes = 0, n_prims = 0;
     for (uint32_t i = c.bid * BLOCK + threadIdx.x; i < count; i += c.nblocks * BLOCK) {
         const uint32_t idx = start + i;
-        if (np.meta[idx] & META_INACTIVE) {
+        const uint32_t meta = np.meta[idx];
+        if (meta & META_INACTIVE) {
             np.prim[idx] = RT_NO_HIT;
             continue;
         }
@@ -418,6 +428,30 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
                     }
                 }
                 cur = stack[(--sp) * BLOCK];
+            }
+        }
+        if (FINALIZE) {
+            bool done = best_id == RT_NO_HIT;
+            uint32_t flag = 0;
+            d3 rgb = mk3(0.0, 0.0, 0.0);
+            if (!done && (meta & META_ILLUM)) {
+                const uint32_t pf = sc.prim_flags[best_id];
+                if ((pf & PRIM_ILLUM_TERMINAL) || level + 1 >= sc.opts.max_depth) {  // children of the last level return zero
+                    done = true;
+                    flag = best_t <= sc.opts.max_occlusion_distance ? 1u : 0u;  // :512-516
+                    if (pf & PRIM_EMISSIVE) {
+                        const rt_material &m = sc.materials[sc.shade_prims[best_id].material];
+                        rgb = mk3(m.emissive[0], m.emissive[1], m.emissive[2]);
+                    }
+                }
+            }
+            if (done) {
+                np.meta[idx] = meta | META_DONE;
+                np.prim[idx] = flag;
+                np.t[idx] = rgb.x;
+                np.bu[idx] = rgb.y;
+                np.bv[idx] = rgb.z;
+                continue;
             }
         }
         np.prim[idx] = best_id;
@@ -514,6 +548,44 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
 //      consecutive records (phase A's per-parent loops wrote 64 strided ones and
 //      left lanes of missed rays idle).  Same for the shadow rays.
 // Child order (parent-major, slot-minor) and RNG keys are unchanged.
+// Wave-level compaction of the nodes that still need work (not META_DONE, not
+// padding): each wave scans 64 nodes at a time, appends the live ones to its own
+// queue in LDS and runs the heavy path only on full groups of 64 (and once on the
+// tail), so the heavy path always has (nearly) all lanes busy.  Purely
+// wave-local: no block barrier.
+struct WaveQueue {
+    uint32_t *q;   // 128 entries of this wave
+    uint32_t n;    // wave-uniform fill
+    uint32_t base; // next node (level-relative) this wave scans
+};
+__device__ __forceinline__ void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// Scans until 64 live nodes are queued or the wave's share of [0,count) is
+// exhausted; returns how many to process now (0 = finished).
+__device__ __forceinline__ uint32_t queue_fill(WaveQueue &wq, const uint32_t *__restrict__ meta, uint32_t start, uint32_t count,
+                                              uint32_t stride, uint32_t lane) {
+    while (wq.n < 64u && wq.base < count) {
+        const uint32_t i = wq.base + lane;
+        const bool live = i < count && !(meta[start + i] & (META_INACTIVE | META_DONE));
+        const unsigned long long mask = __ballot(live);
+        if (live) wq.q[wq.n + __popcll(mask & ((1ull << lane) - 1ull))] = start + i;
+        wq.n += static_cast<uint32_t>(__popcll(mask));
+        wq.base += stride;
+    }
+    wave_sync_lds();
+    return wq.n < 64u ? wq.n : 64u;
+}
+// Drops the first `n_proc` entries.
+__device__ __forceinline__ void queue_pop(WaveQueue &wq, uint32_t n_proc, uint32_t lane) {
+    const uint32_t rest = wq.n - n_proc;
+    uint32_t tmp = 0;
+    if (lane < rest) tmp = wq.q[n_proc + lane];
+    wave_sync_lds();
+    if (lane < rest) wq.q[lane] = tmp;
+    wave_sync_lds();
+    wq.n = rest;
+}
+
 struct ExpandLds {
     double Px[BLOCK], Py[BLOCK], Pz[BLOCK];     // hit point
     double nx[BLOCK], ny[BLOCK], nz[BLOCK];     // shading normal
@@ -537,9 +609,11 @@ __device__ __forceinline__ uint32_t wave_owner(const uint32_t *incl, uint32_t j)
     return lo;
 }
 
+template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, Counters *ctrs,
                                                  Shards shards, uint32_t level) {
     __shared__ ExpandLds L;
+    __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
     const ShardCtx c = shard_ctx(ctrs, shards);
     Counters *ctr = c.ctr;
     if (ctr->overflow) return;
@@ -547,15 +621,19 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
     const bool next_real = level + 1 < sc.opts.max_depth;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
     const uint32_t child_depth = level + 1;
-    for (uint32_t base_i = c.bid * BLOCK; base_i < count; base_i += c.nblocks * BLOCK) {
-        const uint32_t i = base_i + tid;
-        const bool valid = i < count;
-        const uint32_t idx = start + (valid ? i : 0u);
+    WaveQueue wq;
+    wq.q = queue_lds + (tid >> 6) * 128u;
+    wq.n = 0;
+    wq.base = (c.bid * (BLOCK / 64) + (tid >> 6)) * 64u;
+    const uint32_t wave_stride = c.nblocks * BLOCK;
+    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, start, count, wave_stride, lane)) != 0; queue_pop(wq, n_proc, lane)) {
+        const bool valid = lane < n_proc;
+        const uint32_t idx = valid ? wq.q[lane] : start;
         uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0, phong_flag = 0;
         uint32_t prim = RT_NO_HIT, meta = 0;
         if (valid) {
             meta = np.meta[idx];
-            prim = (meta & META_INACTIVE) ? RT_NO_HIT : np.prim[idx];
+            prim = np.prim[idx];
         }
         if (prim != RT_NO_HIT) {
             const bool illum = (meta & META_ILLUM) != 0;
@@ -633,6 +711,11 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
             }
         }
         const uint32_t total = nR + nT + nG;
+        if (COUNT && valid) {  // census of the nodes that reach the heavy path
+            atomicAdd(&ctr->census[level][(meta & META_ILLUM) ? 1 : 0], 1ull);
+            if (prim == RT_NO_HIT) atomicAdd(&ctr->census[level][2], 1ull);
+            if (total + nS == 0) atomicAdd(&ctr->census[level][3], 1ull);
+        }
         L.counts[tid] = nR | (nT << 16) | (nG << 17) | phong_flag;
         L.mask[tid] = mask;
         uint32_t wave_nodes, wave_shadows;
@@ -642,7 +725,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
         const uint64_t node_local = __shfl(child64, 0, 64), shadow_local = __shfl(shadow64, 0, 64);
         if (node_local + wave_nodes > shards.node_cap || shadow_local + wave_shadows > shards.shadow_cap) {
             if (lane == 0) atomicOr(&ctr->overflow, 1u);
-            continue;
+            return;  // the shard is dead for this batch (wave-uniform exit)
         }
         const uint32_t node_base = c.node_off + static_cast<uint32_t>(node_local);
         const uint32_t shadow_base = c.shadow_off + static_cast<uint32_t>(shadow_local);
@@ -739,15 +822,23 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
 // Result: (t,bu,bv) <- RGB, prim <- flag (illumination nodes: occluded).
 __global__ __launch_bounds__(BLOCK) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
                                                   uint32_t level) {
+    __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
     const ShardCtx c = shard_ctx(ctrs, shards);
     Counters *ctr = c.ctr;
     if (ctr->overflow) return;
     const uint32_t start = c.node_off + ctr->level_start[level], count = ctr->level_count[level];
     const bool next_real = level + 1 < sc.opts.max_depth;
-    for (uint32_t i = c.bid * BLOCK + threadIdx.x; i < count; i += c.nblocks * BLOCK) {
-        const uint32_t idx = start + i;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    WaveQueue wq;
+    wq.q = queue_lds + (tid >> 6) * 128u;
+    wq.n = 0;
+    wq.base = (c.bid * (BLOCK / 64) + (tid >> 6)) * 64u;
+    const uint32_t wave_stride = c.nblocks * BLOCK;
+    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, start, count, wave_stride, lane)) != 0; queue_pop(wq, n_proc, lane)) {
+        if (lane >= n_proc) continue;
+        const uint32_t idx = wq.q[lane];
         const uint32_t meta = np.meta[idx];
-        const uint32_t prim = (meta & META_INACTIVE) ? RT_NO_HIT : np.prim[idx];
+        const uint32_t prim = np.prim[idx];
         d3 result = mk3(0.0, 0.0, 0.0);
         uint32_t flag = 0;
         if (prim != RT_NO_HIT) {
