@@ -325,30 +325,40 @@ __device__ __forceinline__ bool hit_triangle(const double *__restrict__ g, uint3
 // Conservative slab test in f32: never rejects a box that contains a primitive
 // whose exact f64 predicate passes within the t limit.
 //   * node boxes are the exact f64 unions rounded outward to f32 (rt_bvh.cpp);
-//   * the ray origin is rounded to f32 (error <= 2^-24 |o|), the subtraction
-//     b - o rounds once more (<= 2^-24 (|b| + |o|)); both, and the rounding of
-//     the primitives' reference-order AABB arithmetic in f64, are absorbed by
-//     widening every slab by P = 2^-20 (|o|_inf + scene scale) on each side;
-//   * inv = 1/d and the product carry a relative error <= 2^-23: entry
-//     distances are lowered and exit distances raised by 2^-21 relative;
-//   * NaNs (0 * inf) drop out of fminf/fmaxf, which keeps the slab;
-//     comparisons are written so that a NaN keeps the node.
+//   * every slab is widened by P = 2^-20 (|o|_inf + scene scale) on each side,
+//     which absorbs the f32 rounding of the origin-side constants (<= 2^-23 |o|)
+//     and the rounding of the primitives' reference-order AABB arithmetic in f64;
+//   * inv = 1/d and the fma carry a relative error <= 2^-23: entry distances are
+//     lowered and exit distances raised by 2^-21 relative;
+//   * |1/d| is clamped to 1e25, so a ray parallel to a slab (d = +-0) gets
+//     entry/exit distances of magnitude >= 1e25 * P with the right signs, no
+//     inf - inf; comparisons are written so that a NaN (NaN ray) keeps the node.
 struct CullRay {
-    float ox, oy, oz;
-    float ix, iy, iz;
-    float P;
+    float ix, iy, iz;        // 1/d, magnitude clamped to 1e25 (keeps every product finite)
+    float x1, x2, y1, y2, z1, z2;  // -(o + P) / d and -(o - P) / d per axis
 };
+
+__device__ __forceinline__ float cull_inv(double d) {
+    const double inv = 1.0 / d;  // +-inf for +-0
+    const double lim = 1e25;     // |t| beyond 1e25 * P is no hit distance of a bounded scene
+    return static_cast<float>(fabs(inv) < lim ? inv : copysign(lim, inv));  // NaN direction -> -/+1e25, still finite
+}
 
 __device__ __forceinline__ CullRay make_cull_ray(const RayD &r, double scene_scale) {
     const double m = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
+    const double P = 0x1.0p-20 * (m + scene_scale);
     CullRay c;
-    c.P = static_cast<float>(0x1.0p-20 * (m + scene_scale));
-    c.ox = static_cast<float>(r.o.x);
-    c.oy = static_cast<float>(r.o.y);
-    c.oz = static_cast<float>(r.o.z);
-    c.ix = static_cast<float>(1.0 / r.d.x);
-    c.iy = static_cast<float>(1.0 / r.d.y);
-    c.iz = static_cast<float>(1.0 / r.d.z);
+    c.ix = cull_inv(r.d.x);
+    c.iy = cull_inv(r.d.y);
+    c.iz = cull_inv(r.d.z);
+    // slab distances are evaluated as fma(b, inv, -(o +- P) * inv): the rounding of
+    // these constants displaces the origin by <= 2^-24 |o|, far inside P
+    c.x1 = static_cast<float>(-(r.o.x + P) * static_cast<double>(c.ix));
+    c.x2 = static_cast<float>(-(r.o.x - P) * static_cast<double>(c.ix));
+    c.y1 = static_cast<float>(-(r.o.y + P) * static_cast<double>(c.iy));
+    c.y2 = static_cast<float>(-(r.o.y - P) * static_cast<double>(c.iy));
+    c.z1 = static_cast<float>(-(r.o.z + P) * static_cast<double>(c.iz));
+    c.z2 = static_cast<float>(-(r.o.z - P) * static_cast<double>(c.iz));
     return c;
 }
 
@@ -360,20 +370,22 @@ __device__ __forceinline__ float cull_limit_f32(double t_limit) {
 
 // `bmin`/`bmax`: 3 floats each.  Returns false when the box can be skipped;
 // *t_entry is the (lowered) entry distance, used to order the children.
+// Per axis: t1 = (bmin - (o + P)) / d, t2 = (bmax - (o - P)) / d -- whichever of
+// the two is the entry is lowered by P/|d|, the exit raised.
 __device__ __forceinline__ bool box_cull_test(const float *__restrict__ bmin, const float *__restrict__ bmax, const CullRay &c,
                                               float t_limit, float *t_entry) {
-    float t1 = ((bmin[0] - c.ox) - c.P) * c.ix, t2 = ((bmax[0] - c.ox) + c.P) * c.ix;
+    float t1 = __builtin_fmaf(bmin[0], c.ix, c.x1), t2 = __builtin_fmaf(bmax[0], c.ix, c.x2);
     float tn = fminf(t1, t2), tf = fmaxf(t1, t2);
-    t1 = ((bmin[1] - c.oy) - c.P) * c.iy;
-    t2 = ((bmax[1] - c.oy) + c.P) * c.iy;
+    t1 = __builtin_fmaf(bmin[1], c.iy, c.y1);
+    t2 = __builtin_fmaf(bmax[1], c.iy, c.y2);
     tn = fmaxf(tn, fminf(t1, t2));
     tf = fminf(tf, fmaxf(t1, t2));
-    t1 = ((bmin[2] - c.oz) - c.P) * c.iz;
-    t2 = ((bmax[2] - c.oz) + c.P) * c.iz;
+    t1 = __builtin_fmaf(bmin[2], c.iz, c.z1);
+    t2 = __builtin_fmaf(bmax[2], c.iz, c.z2);
     tn = fmaxf(tn, fminf(t1, t2));
     tf = fminf(tf, fmaxf(t1, t2));
-    tn = fminf(tn * (1.0f - 0x1.0p-21f), tn * (1.0f + 0x1.0p-21f));  // lowered; +-inf stay +-inf
-    tf = fmaxf(tf * (1.0f - 0x1.0p-21f), tf * (1.0f + 0x1.0p-21f));  // raised
+    tn = __builtin_fmaf(-0x1.0p-21f, fabsf(tn), tn);  // lowered (all values are finite)
+    tf = __builtin_fmaf(0x1.0p-21f, fabsf(tf), tf);   // raised
     *t_entry = tn;
     if (tn > tf) return false;
     if (tf < 0.0f) return false;
