@@ -292,6 +292,9 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev sc, WorkList wl, Node
 // AABB, so the conservative node test has already pre-filtered it (no divisions,
 // running t limit applied); then the primitive test, and only for primitive
 // hits the reference-order AABB arithmetic (6 divisions).
+#ifndef RESOLVE_WAVES
+#define RESOLVE_WAVES 2
+#endif
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 4
 #endif
@@ -639,8 +642,8 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
             const bool illum = (meta & META_ILLUM) != 0;
             const d3 o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
             const d3 d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
-            const ShadePrim sh = sc.shade_prims[prim];
-            const rt_material m = sc.materials[sh.material];
+            const ShadePrim &sh = sc.shade_prims[prim];
+            const rt_material &m = sc.materials[sh.material];
             const Surface s = compute_surface(sc, sh, m.side, o, d, np.t[idx], np.bu[idx], np.bv[idx]);
             d3 refr_dir = mk3(0.0, 0.0, 0.0);
             bool cast_shadows = false;
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
 // ------------------------------------------------------------------ resolve
 // Bottom-up shading of every node of `level`; children of level+1 are resolved.
 // Result: (t,bu,bv) <- RGB, prim <- flag (illumination nodes: occluded).
-__global__ __launch_bounds__(BLOCK) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
+__global__ __launch_bounds__(BLOCK, RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
                                                   uint32_t level) {
     __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
     const ShardCtx c = shard_ctx(ctrs, shards);
@@ -846,8 +849,8 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(SceneDev sc, NodePool np, Sha
             const d3 o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
             const d3 d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
             const double t = np.t[idx], bu = np.bu[idx], bv = np.bv[idx];
-            const ShadePrim sh = sc.shade_prims[prim];
-            const rt_material m = sc.materials[sh.material];
+            const ShadePrim &sh = sc.shade_prims[prim];
+            const rt_material &m = sc.materials[sh.material];
             const Surface s = compute_surface(sc, sh, m.side, o, d, t, bu, bv);
             const d3 mc = material_color(sc, sh, m, s, bu, bv);
             const d3 emissive = mk3(m.emissive[0], m.emissive[1], m.emissive[2]);
@@ -1070,8 +1073,8 @@ __global__ __launch_bounds__(BLOCK) void k_primary_aov(SceneDev sc, WorkList wl,
             out_n[3 * at] = out_n[3 * at + 1] = out_n[3 * at + 2] = 0.0;
             continue;
         }
-        const ShadePrim sh = sc.shade_prims[prim];
-        const rt_material m = sc.materials[sh.material];
+        const ShadePrim &sh = sc.shade_prims[prim];
+        const rt_material &m = sc.materials[sh.material];
         const d3 o = mk3(np.ox[i], np.oy[i], np.oz[i]), d = mk3(np.dx[i], np.dy[i], np.dz[i]);
         const Surface s = compute_surface(sc, sh, m.side, o, d, np.t[i], np.bu[i], np.bv[i]);
         out_t[at] = np.t[i];
