@@ -396,7 +396,8 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     // ---- flatten primitives
     std::vector<ShadePrim> shade(d->n_prims);
     std::vector<PlanePrim> planes;
-    std::vector<Aabb> boxes;
+    std::vector<Aabb> boxes;       // reference AABBs (part of the hit predicate)
+    std::vector<Aabb> cull_boxes;  // what the BVH is built from
     std::vector<uint32_t> bounded_ids;
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const uint32_t type = d->prim_type[i];
@@ -451,24 +452,60 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             }
         }
         boxes.push_back(world_aabb(mn, mx, w));
+        // Box the BVH is built from.  A triangle's reference AABB is the transform of its
+        // object-space box (looser than the triangle when the mesh is rotated); every hit
+        // point lies on the triangle itself, so the bounds of the world-space vertices are
+        // a valid -- and tighter -- culling volume.  The exact predicate keeps the loose box.
+        if (type == RT_PRIM_TRIANGLE) {
+            const double *p = d->tri_pos + 9ull * d->prim_tri[i];
+            Aabb tight{};
+            for (int v = 0; v < 3; ++v) {
+                const double x = p[3 * v], y = p[3 * v + 1], z = p[3 * v + 2];
+                const double q[3] = {w[0] * x + w[1] * y + w[2] * z + w[3], w[4] * x + w[5] * y + w[6] * z + w[7],
+                                     w[8] * x + w[9] * y + w[10] * z + w[11]};
+                for (int k = 0; k < 3; ++k) {
+                    tight.mn[k] = v ? std::fmin(tight.mn[k], q[k]) : q[k];
+                    tight.mx[k] = v ? std::fmax(tight.mx[k], q[k]) : q[k];
+                }
+            }
+            bool finite = true;
+            for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(tight.mn[k]) && std::isfinite(tight.mx[k]);
+            // never larger than the reference box (intersection of two valid volumes)
+            for (int k = 0; finite && k < 3; ++k) {
+                tight.mn[k] = std::fmax(tight.mn[k], boxes.back().mn[k]);
+                tight.mx[k] = std::fmin(tight.mx[k], boxes.back().mx[k]);
+                if (tight.mn[k] > tight.mx[k]) finite = false;
+            }
+            cull_boxes.push_back(finite ? tight : boxes.back());
+        } else {
+            cull_boxes.push_back(boxes.back());
+        }
         bounded_ids.push_back(i);
     }
     if (bounded_ids.size() >= (1ull << 28)) return fail(RT_ERR_UNSUPPORTED, "too many bounded primitives");
 
     // ---- BVH
-    BvhBuildResult bvh = build_bvh(boxes);
+    BvhBuildResult bvh = build_bvh(cull_boxes);
     std::vector<LeafPrim> leaf(bvh.order.size());
     for (size_t j = 0; j < bvh.order.size(); ++j) {
         const uint32_t b = bvh.order[j], pid = bounded_ids[b];
         LeafPrim &lp = leaf[j];
         std::memset(&lp, 0, sizeof(lp));
-        for (int k = 0; k < 3; ++k) {
-            lp.bmin[k] = boxes[b].mn[k];
-            lp.bmax[k] = boxes[b].mx[k];
+        for (int k = 0; k < 3; ++k) {  // BoundingVolume::intersect, bounds.rs:116-121
+            lp.center[k] = (boxes[b].mn[k] + boxes[b].mx[k]) * 0.5;
+            lp.half[k] = (boxes[b].mx[k] - boxes[b].mn[k]) / 2.0;
         }
         const ShadePrim &sh = shade[pid];
-        if (sh.type == RT_PRIM_TRIANGLE) std::memcpy(lp.geom, d->tri_pos + 9ull * sh.tri, 9 * sizeof(double));
-        else lp.geom[0] = sh.param;
+        if (sh.type == RT_PRIM_TRIANGLE) {  // triangle.rs:196-197
+            const double *p = d->tri_pos + 9ull * sh.tri;
+            for (int k = 0; k < 3; ++k) {
+                lp.geom[k] = p[k];
+                lp.geom[3 + k] = p[3 + k] - p[k];
+                lp.geom[6 + k] = p[6 + k] - p[k];
+            }
+        } else {
+            lp.geom[0] = sh.param;
+        }
         lp.prim_id = pid;
         lp.meta = sh.type | (d->materials[sh.material].side << 2) | (sh.xf << 4);
     }
@@ -612,7 +649,7 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
     uint64_t item0 = 0;
     double call_max_nodes = 0.0, call_max_shadows = 0.0;
     // first batch: modest guess, later batches sized from the measured expansion
-    uint64_t batch = std::min<uint64_t>(plan.total_items, std::max<uint64_t>(wl.ns, np.capacity / 96));
+    uint64_t batch = std::min<uint64_t>(plan.total_items, std::max<uint64_t>(wl.ns, np.capacity / 64));
     if (s->est_nodes_per_item > 0.0) {
         double fit = std::min(np.capacity / s->est_nodes_per_item, sp.capacity / std::max(s->est_shadows_per_item, 1e-9));
         batch = std::min<uint64_t>(plan.total_items, std::max<uint64_t>(wl.ns, static_cast<uint64_t>(0.7 * fit)));

@@ -170,13 +170,13 @@ struct RayD {
 };
 
 // BoundingVolume::intersect (bounds.rs:114-152), reference operation order.
-__device__ __forceinline__ bool prim_box_test(const double *__restrict__ bmin, const double *__restrict__ bmax,
+// `center` = (min + max) * 0.5 and `half` = (max - min) / 2.0 come precomputed (host, same f64 ops).
+__device__ __forceinline__ bool prim_box_test(const double *__restrict__ center, const double *__restrict__ half,
                                               const RayD &r, bool has_max, double max_distance) {
-    double cx = (bmin[0] + bmax[0]) * 0.5, cy = (bmin[1] + bmax[1]) * 0.5, cz = (bmin[2] + bmax[2]) * 0.5;
-    double tcx = cx - r.o.x, tcy = cy - r.o.y, tcz = cz - r.o.z;
-    double hx = (bmax[0] - bmin[0]) / 2.0 * rsign(r.d.x);
-    double hy = (bmax[1] - bmin[1]) / 2.0 * rsign(r.d.y);
-    double hz = (bmax[2] - bmin[2]) / 2.0 * rsign(r.d.z);
+    double tcx = center[0] - r.o.x, tcy = center[1] - r.o.y, tcz = center[2] - r.o.z;
+    double hx = half[0] * rsign(r.d.x);
+    double hy = half[1] * rsign(r.d.y);
+    double hz = half[2] * rsign(r.d.z);
 
     double d_near = (tcx - hx) / r.d.x;
     double d_far = (tcx + hx) / r.d.x;
@@ -195,6 +195,23 @@ __device__ __forceinline__ bool prim_box_test(const double *__restrict__ bmin, c
     if (d_near < 0.0 && d_far < 0.0) return false;
     if (has_max && max_distance < d_near) return false;
     return true;
+}
+
+// Sufficient condition for prim_box_test to pass, without its six divisions:
+// the point o + t d of an accepted primitive hit (t >= 0, t <= max_distance for
+// shadow rays) lies inside the box with a margin of 1e-9 relative on every axis.
+// Then on every axis (near plane - o)/d < t < (far plane - o)/d holds by a margin
+// that exceeds the rounding of the reference-order slab arithmetic (a few ulps) a
+// million times, so none of its rejections can fire (d = +-0: the quotients are
+// -inf / +inf).  Flat boxes (half = 0 on an axis) and hits on a box face never
+// qualify and take the exact test.
+__device__ __forceinline__ bool prim_box_surely_passes(const double *__restrict__ center, const double *__restrict__ half,
+                                                       const RayD &r, double t) {
+    const double px = r.o.x + r.d.x * t, py = r.o.y + r.d.y * t, pz = r.o.z + r.d.z * t;
+    const double ex = 1e-9 * (fabs(r.o.x) + fabs(center[0]) + half[0]);
+    const double ey = 1e-9 * (fabs(r.o.y) + fabs(center[1]) + half[1]);
+    const double ez = 1e-9 * (fabs(r.o.z) + fabs(center[2]) + half[2]);
+    return fabs(px - center[0]) <= half[0] - ex && fabs(py - center[1]) <= half[1] - ey && fabs(pz - center[2]) <= half[2] - ez;
 }
 
 struct HitRec {
@@ -298,8 +315,8 @@ __device__ __forceinline__ bool hit_plane(d3 normal, uint32_t side, bool shadow,
 __device__ __forceinline__ bool hit_triangle(const double *__restrict__ g, uint32_t side, bool shadow, const RayD &r,
                                              bool has_max, double max_distance, HitRec *h) {
     d3 p0 = mk3(g[0], g[1], g[2]);
-    d3 e1 = mk3(g[3], g[4], g[5]) - p0;
-    d3 e2 = mk3(g[6], g[7], g[8]) - p0;
+    d3 e1 = mk3(g[3], g[4], g[5]);  // p1 - p0, p2 - p0: precomputed on the host (same f64 subtraction)
+    d3 e2 = mk3(g[6], g[7], g[8]);
     d3 pv = cross3(r.d, e2);
     double det = dot3(e1, pv);
     bool reject;

@@ -40,9 +40,13 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
 // Leaf primitive record (bounded primitives only), BVH-leaf order.
 //   meta: bits 0..1 type, bits 2..3 side, bits 4..31 transform index
-//   geom: triangle p0 p1 p2 (object space) | geom[0] = sphere radius / cube size
+//   geom: triangle p0, e1 = p1 - p0, e2 = p2 - p0 (object space; the edges are the
+//         first thing triangle.rs:196-197 computes) | geom[0] = sphere radius / cube size
+//   center / half: the primitive's own world AABB (bounds.rs:40-72) in the form its
+//         slab test uses it: (min + max) * 0.5 and (max - min) / 2 (bounds.rs:116-121),
+//         evaluated once on the host with the same f64 operations
 struct alignas(16) LeafPrim {
-    double bmin[3], bmax[3];  // the primitive's own world AABB (bounds.rs:40-72)
+    double center[3], half[3];
     double geom[9];
     uint32_t prim_id;
     uint32_t meta;

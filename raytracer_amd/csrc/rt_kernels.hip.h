@@ -322,7 +322,8 @@ __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPri
     else if (type == RT_PRIM_SPHERE) hit = hit_sphere(lp->geom[0], side, SHADOW, cache.r, SHADOW, max_distance, h);
     else hit = hit_cube(lp->geom[0], side, SHADOW, cache.r, SHADOW, max_distance, h);
     if (!hit) return false;
-    return prim_box_test(lp->bmin, lp->bmax, ray, SHADOW, max_distance);
+    if (prim_box_surely_passes(lp->center, lp->half, ray, h->t)) return true;
+    return prim_box_test(lp->center, lp->half, ray, SHADOW, max_distance);
 }
 
 __device__ __forceinline__ double cull_limit(double t) { return t + 1e-9 * (1.0 + fabs(t)); }
