@@ -524,6 +524,10 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     dev.n_bounded = static_cast<uint32_t>(bounded_ids.size());
     dev.n_prims = d->n_prims;
     dev.scene_scale = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        dev.q_origin[k] = bvh.q_origin[k];
+        dev.q_scale[k] = bvh.q_scale[k];
+    }
     if (!boxes.empty())
         for (int k = 0; k < 3; ++k)
             dev.scene_scale = std::fmax(dev.scene_scale, std::fmax(std::fabs(bvh.root_box.mn[k]), std::fabs(bvh.root_box.mx[k])));

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <utility>
 #include <limits>
 
 namespace rt {
@@ -33,6 +34,7 @@ struct Builder {
     std::vector<uint32_t> order;
     std::vector<double> cx, cy, cz;
     BvhBuildResult out;
+    std::vector<std::pair<Aabb, Aabb>> child_boxes;  // exact f64 child boxes per node
 
     explicit Builder(const std::vector<Aabb> &b) : boxes(b) {}
 
@@ -171,19 +173,14 @@ struct Builder {
 
         uint32_t self = static_cast<uint32_t>(out.nodes.size());
         out.nodes.emplace_back();
+        child_boxes.emplace_back();
         Aabb lb, rb;
         uint32_t l = build(first, mid - first, depth + 1, &lb);
         uint32_t r = build(mid, first + count - mid, depth + 1, &rb);
         BvhNode &n = out.nodes[self];
-        for (int k = 0; k < 3; ++k) {
-            n.lmin[k] = round_down(lb.mn[k]);
-            n.lmax[k] = round_up(lb.mx[k]);
-            n.rmin[k] = round_down(rb.mn[k]);
-            n.rmax[k] = round_up(rb.mx[k]);
-        }
         n.left = l;
         n.right = r;
-        for (uint32_t &p : n._pad) p = 0;
+        child_boxes[self] = {lb, rb};  // quantised once the root box (= the frame) is known
         return self;
     }
 };
@@ -209,6 +206,41 @@ BvhBuildResult build_bvh(const std::vector<Aabb> &boxes) {
     b.out.root_ref = b.build(0, n, 0, &root);
     b.out.root_box = root;
     b.out.order = std::move(b.order);
+    // ---- quantisation frame: the root box, 65535 steps per axis
+    double origin[3], scale[3];
+    for (int k = 0; k < 3; ++k) {
+        b.out.q_origin[k] = round_down(root.mn[k]);
+        origin[k] = static_cast<double>(b.out.q_origin[k]);
+        double extent = root.mx[k] - origin[k];
+        if (!(extent > 0.0) || !std::isfinite(extent)) extent = 1.0;
+        b.out.q_scale[k] = round_up(extent / 65535.0 * (1.0 + 1e-6));
+        scale[k] = static_cast<double>(b.out.q_scale[k]);
+    }
+    // origin + q * scale <= x for minima (>= for maxima), in exact arithmetic on the stored f32 frame
+    auto q_down = [&](double x, int k) -> uint16_t {
+        double q = std::floor((x - origin[k]) / scale[k]);
+        if (!(q > 0.0)) return 0;  // also NaN
+        if (q > 65535.0) q = 65535.0;
+        while (q > 0.0 && origin[k] + q * scale[k] > x) q -= 1.0;
+        return static_cast<uint16_t>(q);
+    };
+    auto q_up = [&](double x, int k) -> uint16_t {
+        double q = std::ceil((x - origin[k]) / scale[k]);
+        if (!(q < 65535.0)) return 65535;  // also NaN
+        if (q < 0.0) q = 0.0;
+        while (q < 65535.0 && origin[k] + q * scale[k] < x) q += 1.0;
+        return static_cast<uint16_t>(q);
+    };
+    for (size_t i = 0; i < b.out.nodes.size(); ++i) {
+        BvhNode &n = b.out.nodes[i];
+        const Aabb &lb = b.child_boxes[i].first, &rb = b.child_boxes[i].second;
+        for (int k = 0; k < 3; ++k) {
+            n.lmin[k] = q_down(lb.mn[k], k);
+            n.lmax[k] = q_up(lb.mx[k], k);
+            n.rmin[k] = q_down(rb.mn[k], k);
+            n.rmax[k] = q_up(rb.mx[k], k);
+        }
+    }
     return std::move(b.out);
 }
 

@@ -19,6 +19,7 @@ struct BvhBuildResult {
     uint32_t max_depth = 0;
     uint32_t n_leaves = 0;
     Aabb root_box{};
+    float q_origin[3] = {0, 0, 0}, q_scale[3] = {1, 1, 1};  // quantisation frame of the node boxes
 };
 
 // boxes: world AABBs of the bounded primitives.  Depth never exceeds

@@ -341,7 +341,8 @@ __device__ __forceinline__ bool hit_triangle(const double *__restrict__ g, uint3
 // ------------------------------------------------------------------ BVH node culling
 // Conservative slab test in f32: never rejects a box that contains a primitive
 // whose exact f64 predicate passes within the t limit.
-//   * node boxes are the exact f64 unions rounded outward to f32 (rt_bvh.cpp);
+//   * node boxes are the exact f64 unions rounded outward to 16-bit fixed point in
+//     the scene frame (rt_bvh.cpp): looser by at most extent/65535 per side;
 //   * every slab is widened by P = 2^-20 (|o|_inf + scene scale) on each side,
 //     which absorbs the f32 rounding of the origin-side constants (<= 2^-23 |o|)
 //     and the rounding of the primitives' reference-order AABB arithmetic in f64;
@@ -351,31 +352,33 @@ __device__ __forceinline__ bool hit_triangle(const double *__restrict__ g, uint3
 //     entry/exit distances of magnitude >= 1e25 * P with the right signs, no
 //     inf - inf; comparisons are written so that a NaN (NaN ray) keeps the node.
 struct CullRay {
-    float ix, iy, iz;        // 1/d, magnitude clamped to 1e25 (keeps every product finite)
-    float x1, x2, y1, y2, z1, z2;  // -(o + P) / d and -(o - P) / d per axis
+    float ax, ay, az;              // q_scale / d per axis, |1/d| clamped to 1e25 (keeps every product finite)
+    float x1, x2, y1, y2, z1, z2;  // (q_origin - (o + P)) / d and (q_origin - (o - P)) / d per axis
 };
 
-__device__ __forceinline__ float cull_inv(double d) {
+__device__ __forceinline__ double cull_inv(double d) {
     const double inv = 1.0 / d;  // +-inf for +-0
     const double lim = 1e25;     // |t| beyond 1e25 * P is no hit distance of a bounded scene
-    return static_cast<float>(fabs(inv) < lim ? inv : copysign(lim, inv));  // NaN direction -> -/+1e25, still finite
+    return fabs(inv) < lim ? inv : copysign(lim, inv);  // NaN direction -> +-1e25, still finite
 }
 
-__device__ __forceinline__ CullRay make_cull_ray(const RayD &r, double scene_scale) {
+// Slab distances are evaluated as fma(q, a, c) with q the 16-bit box coordinate:
+// (q_origin + q q_scale - (o +- P)) / d.  The f32 rounding of a and c displaces
+// the box by <= 2^-23 (scene scale + |o|), far inside P.
+__device__ __forceinline__ CullRay make_cull_ray(const RayD &r, double scene_scale, const float *q_origin, const float *q_scale) {
     const double m = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
     const double P = 0x1.0p-20 * (m + scene_scale);
+    const double ix = cull_inv(r.d.x), iy = cull_inv(r.d.y), iz = cull_inv(r.d.z);
     CullRay c;
-    c.ix = cull_inv(r.d.x);
-    c.iy = cull_inv(r.d.y);
-    c.iz = cull_inv(r.d.z);
-    // slab distances are evaluated as fma(b, inv, -(o +- P) * inv): the rounding of
-    // these constants displaces the origin by <= 2^-24 |o|, far inside P
-    c.x1 = static_cast<float>(-(r.o.x + P) * static_cast<double>(c.ix));
-    c.x2 = static_cast<float>(-(r.o.x - P) * static_cast<double>(c.ix));
-    c.y1 = static_cast<float>(-(r.o.y + P) * static_cast<double>(c.iy));
-    c.y2 = static_cast<float>(-(r.o.y - P) * static_cast<double>(c.iy));
-    c.z1 = static_cast<float>(-(r.o.z + P) * static_cast<double>(c.iz));
-    c.z2 = static_cast<float>(-(r.o.z - P) * static_cast<double>(c.iz));
+    c.ax = static_cast<float>(static_cast<double>(q_scale[0]) * ix);
+    c.ay = static_cast<float>(static_cast<double>(q_scale[1]) * iy);
+    c.az = static_cast<float>(static_cast<double>(q_scale[2]) * iz);
+    c.x1 = static_cast<float>((static_cast<double>(q_origin[0]) - (r.o.x + P)) * ix);
+    c.x2 = static_cast<float>((static_cast<double>(q_origin[0]) - (r.o.x - P)) * ix);
+    c.y1 = static_cast<float>((static_cast<double>(q_origin[1]) - (r.o.y + P)) * iy);
+    c.y2 = static_cast<float>((static_cast<double>(q_origin[1]) - (r.o.y - P)) * iy);
+    c.z1 = static_cast<float>((static_cast<double>(q_origin[2]) - (r.o.z + P)) * iz);
+    c.z2 = static_cast<float>((static_cast<double>(q_origin[2]) - (r.o.z - P)) * iz);
     return c;
 }
 
@@ -385,20 +388,20 @@ __device__ __forceinline__ float cull_limit_f32(double t_limit) {
     return f + fabsf(f) * 0x1.0p-21f;  // inf stays inf
 }
 
-// `bmin`/`bmax`: 3 floats each.  Returns false when the box can be skipped;
-// *t_entry is the (lowered) entry distance, used to order the children.
+// `bmin`/`bmax`: 3 quantised coordinates each.  Returns false when the box can be
+// skipped; *t_entry is the (lowered) entry distance, used to order the children.
 // Per axis: t1 = (bmin - (o + P)) / d, t2 = (bmax - (o - P)) / d -- whichever of
 // the two is the entry is lowered by P/|d|, the exit raised.
-__device__ __forceinline__ bool box_cull_test(const float *__restrict__ bmin, const float *__restrict__ bmax, const CullRay &c,
+__device__ __forceinline__ bool box_cull_test(const uint16_t *__restrict__ bmin, const uint16_t *__restrict__ bmax, const CullRay &c,
                                               float t_limit, float *t_entry) {
-    float t1 = __builtin_fmaf(bmin[0], c.ix, c.x1), t2 = __builtin_fmaf(bmax[0], c.ix, c.x2);
+    float t1 = __builtin_fmaf(static_cast<float>(bmin[0]), c.ax, c.x1), t2 = __builtin_fmaf(static_cast<float>(bmax[0]), c.ax, c.x2);
     float tn = fminf(t1, t2), tf = fmaxf(t1, t2);
-    t1 = __builtin_fmaf(bmin[1], c.iy, c.y1);
-    t2 = __builtin_fmaf(bmax[1], c.iy, c.y2);
+    t1 = __builtin_fmaf(static_cast<float>(bmin[1]), c.ay, c.y1);
+    t2 = __builtin_fmaf(static_cast<float>(bmax[1]), c.ay, c.y2);
     tn = fmaxf(tn, fminf(t1, t2));
     tf = fminf(tf, fmaxf(t1, t2));
-    t1 = __builtin_fmaf(bmin[2], c.iz, c.z1);
-    t2 = __builtin_fmaf(bmax[2], c.iz, c.z2);
+    t1 = __builtin_fmaf(static_cast<float>(bmin[2]), c.az, c.z1);
+    t2 = __builtin_fmaf(static_cast<float>(bmax[2]), c.az, c.z2);
     tn = fmaxf(tn, fminf(t1, t2));
     tf = fminf(tf, fmaxf(t1, t2));
     tn = __builtin_fmaf(-0x1.0p-21f, fabsf(tn), tn);  // lowered (all values are finite)

@@ -26,17 +26,19 @@ constexpr uint32_t LEAF_FLAG = 0x80000000u;
 constexpr uint32_t SLOT_REFRACTION = 0x40000000u;
 constexpr uint32_t SLOT_GI = 0x80000000u;
 
-// BVH2 node: boxes of both children in f32, rounded OUTWARD from the exact f64
-// unions of the primitives' world AABBs, + child references.  Node boxes only
-// cull (conservatively); every hit decision is taken in f64 at the leaves.
+// BVH2 node, 32 bytes = two 16-byte loads per visit (the traversal kernels are bound
+// by vector-memory instruction issue, not by bytes): both children's boxes as
+// 16-bit fixed point in the scene frame (SceneDev::q_origin / q_scale), minima
+// rounded down and maxima rounded up from the exact f64 unions of the
+// primitives' culling boxes, + child references.  Node boxes only cull
+// (conservatively); every hit decision is taken in f64 at the leaves.
 // ref: bit31 set -> leaf, bits 28..30 = count-1, bits 0..27 = first leaf record.
 struct alignas(16) BvhNode {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
+    uint16_t lmin[3], lmax[3];
+    uint16_t rmin[3], rmax[3];
     uint32_t left, right;
-    uint32_t _pad[2];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 bytes");
 
 // Leaf primitive record (bounded primitives only), BVH-leaf order.
 //   meta: bits 0..1 type, bits 2..3 side, bits 4..31 transform index
@@ -104,6 +106,8 @@ struct SceneDev {
     uint32_t n_bounded;
     uint32_t n_prims;
     double scene_scale;   // max |coordinate| of the root box
+    float q_origin[3];    // node boxes: coordinate = q_origin + q * q_scale (q = 0..65535)
+    float q_scale[3];
     // shading
     const ShadePrim *shade_prims;
     const uint32_t *prim_flags;  // primitive-ID order, PRIM_* bits

@@ -322,8 +322,12 @@ __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPri
     else if (type == RT_PRIM_SPHERE) hit = hit_sphere(lp->geom[0], side, SHADOW, cache.r, SHADOW, max_distance, h);
     else hit = hit_cube(lp->geom[0], side, SHADOW, cache.r, SHADOW, max_distance, h);
     if (!hit) return false;
-    if (prim_box_surely_passes(lp->center, lp->half, ray, h->t)) return true;
-    return prim_box_test(lp->center, lp->half, ray, SHADOW, max_distance);
+    // centre / half-extent: three 16-byte loads (the kernels are bound by vector-memory instruction issue)
+    const double2 *q = reinterpret_cast<const double2 *>(lp);
+    const double2 q0 = q[0], q1 = q[1], q2 = q[2];
+    const double center[3] = {q0.x, q0.y, q1.x}, half[3] = {q1.y, q2.x, q2.y};
+    if (prim_box_surely_passes(center, half, ray, h->t)) return true;
+    return prim_box_test(center, half, ray, SHADOW, max_distance);
 }
 
 __device__ __forceinline__ double cull_limit(double t) { return t + 1e-9 * (1.0 + fabs(t)); }
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
         }
 
         if (sc.root_ref != 0xFFFFFFFFu) {
-            const CullRay cr = make_cull_ray(ray, sc.scene_scale);
+            const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
             ObjRayCache cache;
             cache.xf = 0xFFFFFFFFu;
             stack[0] = STACK_SENTINEL;
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
                 occluded = true;
         }
         if (!occluded && sc.root_ref != 0xFFFFFFFFu) {
-            const CullRay cr = make_cull_ray(ray, sc.scene_scale);
+            const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
             const float limit = cull_limit_f32(cull_limit(tmax));
             ObjRayCache cache;
             cache.xf = 0xFFFFFFFFu;
