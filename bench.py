@@ -45,7 +45,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "scene.json"))
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "scene.json"),
+                    help="scene JSON, or 'synthetic' = BASELINE config 5 (1,000,000-triangle height field, generated on the fly; "
+                         "3840x2160 64 spp unless --size/--spp say otherwise)")
     ap.add_argument("--spp", type=int, default=0, help="override samples_per_pixel (0 = scene file)")
     ap.add_argument("--size", type=int, default=0, help="override width=height (0 = scene file)")
     ap.add_argument("--tile", type=int, default=32)
@@ -76,12 +78,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    config_tag = "BASELINE configs[2]"
+    if args.scene == "synthetic":
+        import tempfile
+
+        from raytracer_amd import synthetic
+
+        out_dir = os.path.join(tempfile.gettempdir(), "mi355rt_synthetic")
+        if rank == 0:
+            args.scene = synthetic.write_scene(out_dir)
+        if dist is not None:
+            dist.barrier()
+        args.scene = synthetic.write_scene(out_dir)  # the OBJ exists now; rewrites only the small JSON
+        config_tag = "BASELINE configs[4], procedural"
     scene = host.LoadedScene.from_file(args.scene)
     if args.spp:
         scene.set_option("samples_per_pixel", args.spp)
-    if args.size:
+    if args.size:  # square unless the scene is wider than tall (keeps the aspect of the 4K synthetic frame)
+        aspect = scene.opts.height / scene.opts.width
         scene.set_option("width", args.size)
-        scene.set_option("height", args.size)
+        scene.set_option("height", max(1, round(args.size * aspect)))
     w, h, spp = int(scene.opts.width), int(scene.opts.height), int(scene.opts.samples_per_pixel)
     gpu = device.DeviceScene(scene.desc, pool_bytes=int(args.pool_gib * (1 << 30)) or None)
     accum = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
@@ -128,12 +144,12 @@ def main():
     if rank == 0:
         value = rays / elapsed / 1e6
         out = {
-            "metric": "Mrays/sec (whole node) on scene.json 800x800 4spp", "value": round(value, 3), "unit": "Mrays/s",
+            "metric": f"Mrays/sec (whole node) on {os.path.basename(args.scene)} {w}x{h} {spp}spp", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"{os.path.basename(args.scene)} {w}x{h} {spp}spp, {scene.n_prims} primitives, "
-                            f"{rays // max(1, args.steps)} rays/frame (BASELINE configs[2]); scene resident in HBM, frame reduced to rank 0",
+                            f"{rays // max(1, args.steps)} rays/frame ({config_tag}); scene resident in HBM, frame reduced to rank 0",
                 "parallelism": f"tiles{world}" + (f"xsamples{args.sample_shards}" if args.sample_shards > 1 else ""),
                 "tile": args.tile, "rays_per_step": rays // max(1, args.steps),
             },
@@ -164,7 +180,8 @@ def main():
         achieved = k_rays * k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        default_workload = os.path.basename(args.scene) == "scene.json" and not args.spp and not args.size
+        if default_workload and os.path.exists(pmc_path):  # the PMC passes were taken on this workload only
             try:
                 traffic = json.load(open(pmc_path)).get("k_trace_" + kern, {}).get("hbm_bytes_per_launch")
             except Exception:
@@ -186,7 +203,12 @@ def main():
 
             cores = min(16, os.cpu_count() or 1)
             cpu = ob.OracleScene(scene.desc)
-            y0, y1 = 0, h  # the whole frame: ~3-4 s on 16 host cores (~1 core-minute of CPU work)
+            # bounded sample: the whole frame when that is ~10 s of CPU work (scene.json: ~3-4 s on 16 host
+            # cores), otherwise a centred band of rows of the same frame sized for ~10-30 s of CPU work
+            rays_frame = rays // max(1, args.steps)
+            rows = max(1, min(h, int(h * min(1.0, 10.0 * 15e6 / max(1, rays_frame)))))
+            y0 = (h - rows) // 2
+            y1 = y0 + rows
             p = _abi.RenderParams(seed=0, x0=0, y0=y0, x1=w, y1=y1)
             t0 = time.perf_counter()
             _, _, n_cpu = cpu.render(p, mode=ob.MODE_KD, threads=cores, want_rgba=False)
