@@ -7,8 +7,9 @@
 A step is ONE frame of scenes/scene.json (800x800, 4 spp, 1,524 primitives,
 ~147 M rays; BASELINE configs[2]): the scene is resident in HBM, every rank
 renders its Morton-interleaved tile shard into a zeroed f64 accumulation buffer
-through the C ABI (rt_render_device), one RCCL reduce(SUM) assembles the frame
-on rank 0, rank 0 tonemaps to RGBA8 on the device.  Total work is fixed as N
+through the C ABI (rt_render_device), one RCCL collective assembles the frame on
+rank 0 (gather of each rank's own tiles; reduce(SUM) of the frames when samples
+are sharded too), rank 0 tonemaps to RGBA8 on the device.  Total work is fixed as N
 grows ("strong" scaling).  value = rays of all ranks / max-over-ranks time.
 
 Rank 0 prints one JSON line; with N = 1 it also carries
@@ -113,11 +114,13 @@ def main():
 
     def step(flags=0):
         accum.zero_()
-        total, _ = distributed.render_frame(lambda p, a: render_local(p, a, flags), accum, rank, world, spp, seed=0,
-                                            tile_size=args.tile, sample_shards=args.sample_shards, dist=dist)
+        # frame exchange inside (gather of own tiles / reduce of frames); the ray counters are summed once per run
+        _, local = distributed.render_frame(lambda p, a: render_local(p, a, flags), accum, rank, world, spp, seed=0,
+                                            tile_size=args.tile, sample_shards=args.sample_shards, dist=dist, opts=scene.opts,
+                                            reduce_count=False)
         if rank == 0:
             gpu.tonemap_device(accum.data_ptr(), rgba.data_ptr(), stream=stream)
-        return total
+        return local
 
     def fence():
         if dist is not None:
@@ -138,6 +141,9 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        cnt = torch.tensor([rays], dtype=torch.int64, device="cuda")
+        dist.reduce(cnt, dst=0, op=dist.ReduceOp.SUM)
+        rays = int(cnt.item())
 
     timed_stats = list(stats_log)
     out = None

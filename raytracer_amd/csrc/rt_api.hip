@@ -350,7 +350,10 @@ Shards plan_shards(const rt_scene *s, uint64_t n, uint32_t ns) {
 }
 
 // dynamic LDS of the traversal kernels: per-lane stack of (max leaf depth + 2) entries (sentinel included)
-uint32_t stack_lds_bytes(const rt_scene *s) { return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t); }
+uint32_t stack_lds_bytes(const rt_scene *s) {
+    static const uint32_t extra = std::getenv("MI355RT_EXTRA_LDS") ? std::atoi(std::getenv("MI355RT_EXTRA_LDS")) : 0;  // occupancy experiments
+    return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + extra;
+}
 
 Shards single_shard(const rt_scene *s) { return Shards{1u, s->np.capacity, s->sp.capacity, 1u}; }
 
@@ -723,7 +726,14 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
             c.prims_tested_shadow += ck.prims_tested_shadow;
             for (uint32_t l = 0; l < MAX_LEVELS; ++l)
                 for (uint32_t q = 0; q < 4; ++q) c.census[l][q] += ck.census[l][q];
+            c.wave_node_steps += ck.wave_node_steps;
+            c.wave_leaf_rounds += ck.wave_leaf_rounds;
+            c.wave_iterations += ck.wave_iterations;
+            c.wave_max_steps = std::max(c.wave_max_steps, ck.wave_max_steps);
         }
+        if (count_work && std::getenv("MI355RT_CENSUS"))
+            std::fprintf(stderr, "[mi355rt census] closest kernel, wave level: %llu node visits, %llu leaf rounds over %llu waves (all levels); busiest wave %llu node visits\n",
+                         c.wave_node_steps, c.wave_leaf_rounds, c.wave_iterations, c.wave_max_steps);
         if (count_work && std::getenv("MI355RT_CENSUS"))
             for (uint32_t l = 0; l < max_depth && l < MAX_LEVELS; ++l)
                 std::fprintf(stderr, "[mi355rt census] level %u: colour %llu illum %llu miss %llu no-emit %llu\n", l, c.census[l][0],

@@ -178,6 +178,8 @@ struct Counters {
     // RT_FLAG_COUNT_WORK census per level: [0] colour nodes, [1] illumination nodes,
     // [2] misses, [3] nodes that emit neither children nor shadow rays
     unsigned long long census[MAX_LEVELS][4];
+    // RT_FLAG_COUNT_WORK, closest-hit kernel, wave level: node visits, leaf rounds, waves that ran, node visits of the busiest wave
+    unsigned long long wave_node_steps, wave_leaf_rounds, wave_iterations, wave_max_steps;
 };
 
 // The wavefront pools are split into `count` shards.  A shard is an independent

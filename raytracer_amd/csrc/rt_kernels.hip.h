@@ -208,6 +208,7 @@ __global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
     ctr->nodes_visited_shadow = ctr->prims_tested_shadow = 0;
     for (uint32_t l = 0; l < MAX_LEVELS; ++l)
         for (uint32_t q = 0; q < 4; ++q) ctr->census[l][q] = 0;
+    ctr->wave_node_steps = ctr->wave_leaf_rounds = ctr->wave_iterations = ctr->wave_max_steps = 0;
 }
 
 __global__ void k_advance_level(Counters *ctrs, Shards sh, uint32_t level) {
@@ -338,7 +339,10 @@ __device__ __forceinline__ uint32_t descend(const SceneDev &sc, const CullRay &c
                                             uint32_t &sp, unsigned long long &n_nodes) {
     while (!(cur & LEAF_FLAG) && cur != STACK_SENTINEL) {
         const BvhNode *nd = sc.nodes + cur;
-        if (COUNT) n_nodes++;
+        if (COUNT) {  // low 40 bits: lane-level visits; high bits: wave-level visits (counted by the first active lane)
+            n_nodes++;
+            if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(__ballot(true)) - 1)) n_nodes += 1ull << 40;
+        }
         float tl, tr;
         const bool hl = box_cull_test(nd->lmin, nd->lmax, cr, limit, &tl);
         const bool hr = box_cull_test(nd->rmin, nd->rmax, cr, limit, &tr);
@@ -419,6 +423,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
                 cur = descend<COUNT>(sc, cr, cull_limit_f32(cull_limit(best_t)), cur, stack, sp, n_nodes);
                 if (cur == STACK_SENTINEL) break;
                 const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
+                if (COUNT && (threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(__ballot(true)) - 1)) n_prims += 1ull << 40;  // wave-level leaf round
                 for (uint32_t k = 0; k < n; ++k) {
                     const LeafPrim *lp = sc.leaf_prims + first + k;
                     HitRec h;
@@ -468,8 +473,19 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
         np.bv[idx] = best_bv;
     }
     if (COUNT) {
-        atomicAdd(&ctr->nodes_visited_closest, n_nodes);
-        atomicAdd(&ctr->prims_tested_closest, n_prims);
+        atomicAdd(&ctr->nodes_visited_closest, n_nodes & ((1ull << 40) - 1ull));
+        atomicAdd(&ctr->prims_tested_closest, n_prims & ((1ull << 40) - 1ull));
+        unsigned long long ws = n_nodes >> 40, wl = n_prims >> 40;  // wave-level totals
+        for (int off = 32; off >= 1; off >>= 1) {
+            ws += __shfl_xor(ws, off, 64);
+            wl += __shfl_xor(wl, off, 64);
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            atomicAdd(&ctr->wave_node_steps, ws);
+            atomicAdd(&ctr->wave_leaf_rounds, wl);
+            atomicMax(&ctr->wave_max_steps, ws);
+            atomicAdd(&ctr->wave_iterations, 1ull);
+        }
     }
 }
 
@@ -538,7 +554,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
         else sp_pool.occluded[i] = occluded ? 1 : 0;
     }
     if (COUNT) {
-        atomicAdd(&ctr->nodes_visited_shadow, n_nodes);
+        atomicAdd(&ctr->nodes_visited_shadow, n_nodes & ((1ull << 40) - 1ull));
         atomicAdd(&ctr->prims_tested_shadow, n_prims);
     }
 }

@@ -4,10 +4,11 @@
 The path shards with no exchange during tracing (pixels and samples are
 independent): every rank renders a disjoint, Morton-interleaved
 set of tiles (and, for high sample counts, a disjoint sample range of them)
-into a zero-initialised full-frame f64 accumulation buffer; ONE reduce(SUM) to
-rank 0 assembles the frame, one more sums the ray counters.  The sum is exact
-for tile shards (every pixel has one non-zero contributor) and equal up to f64
-re-association for sample shards.
+into a zero-initialised full-frame f64 accumulation buffer; ONE collective
+assembles the frame on rank 0 -- a gather of each rank's own tiles for pure tile
+shards (every pixel has one contributor), a reduce(SUM) of the frames when the
+sample range is split too (equal up to f64 re-association) -- and one reduce sums
+the ray counters.
 """
 import ctypes as C
 
@@ -50,18 +51,77 @@ def shard_tiles(opts, params):
     return xy, int(tw.value), int(th.value)
 
 
-def render_frame(render_local, accum, rank, world, spp, seed=0, tile_size=32, sample_shards=1, dist=None):
+_INDEX_CACHE = {}
+
+
+def _tile_pixels(opts, params, pad_tiles, device):
+    """Flat pixel indices [pad_tiles * tw * th] of a shard's tiles (row-major inside a tile) and their
+    validity (pixels of partial edge tiles / padding tiles are invalid and point at pixel 0)."""
+    import torch
+
+    xy, tw, th = shard_tiles(opts, params)
+    w, h = int(opts.width), int(opts.height)
+    idx = np.zeros((pad_tiles, th, tw), np.int64)
+    ok = np.zeros((pad_tiles, th, tw), bool)
+    for t, (x0, y0) in enumerate(xy):
+        ys, xs = np.arange(y0, y0 + th)[:, None], np.arange(x0, x0 + tw)[None, :]
+        v = (ys < h) & (xs < w)
+        idx[t] = np.where(v, ys * w + xs, 0)
+        ok[t] = v
+    return torch.from_numpy(idx.reshape(-1)).to(device), torch.from_numpy(ok.reshape(-1)).to(device)
+
+
+def _gather_plan(opts, world, spp, seed, tile_size, device):
+    key = (int(opts.width), int(opts.height), world, tile_size, str(device))
+    plan = _INDEX_CACHE.get(key)
+    if plan is None:
+        counts = [len(shard_tiles(opts, shard_params(r, world, spp, seed, tile_size))[0]) for r in range(world)]
+        pad = max(1, max(counts))
+        plan = [_tile_pixels(opts, shard_params(r, world, spp, seed, tile_size), pad, device) for r in range(world)]
+        _INDEX_CACHE[key] = plan
+    return plan
+
+
+def render_frame(render_local, accum, rank, world, spp, seed=0, tile_size=32, sample_shards=1, dist=None, opts=None,
+                 reduce_count=True):
     """Render this rank's shard with `render_local(params, accum) -> ray_count`
-    and reduce to rank 0.  `accum` is a zero-initialised torch tensor [h,w,3]
-    float64 on the rank's device.  Returns (total_ray_count on rank 0, local count)."""
+    and assemble the frame on rank 0.  `accum` is a zero-initialised torch tensor
+    [h,w,3] float64 on the rank's device.  Returns (total_ray_count on rank 0, local count).
+
+    Exchange step: with pure tile shards every pixel has exactly one contributor,
+    so (when `opts` = the scene's rt_render_options is given) each rank sends only
+    its own tiles -- 1/world of the frame -- to rank 0 in ONE gather, point to
+    point over xGMI, and rank 0 scatters them into place: bit-identical to a
+    reduce(SUM) of the full frames at 1/world of the bytes per link.  With sample
+    shards pixels have several contributors and the full frames are reduce(SUM)ed.
+    `reduce_count=False` leaves the ray counters to the caller (one reduce per
+    run instead of one per frame)."""
     import torch
 
     params = shard_params(rank, world, spp, seed, tile_size, sample_shards)
     local = int(render_local(params, accum))
     total = local
     if world > 1:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-        cnt = torch.tensor([local], dtype=torch.int64, device=accum.device)
-        dist.reduce(cnt, dst=0, op=dist.ReduceOp.SUM)
-        total = int(cnt.item())
+        if sample_shards == 1 and opts is not None:
+            plan = _gather_plan(opts, world, spp, seed, tile_size, accum.device)
+            flat = accum.view(-1, 3)
+            mine = flat[plan[rank][0]]
+            parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            try:
+                dist.gather(mine, parts, dst=0)
+            except (RuntimeError, NotImplementedError) as e:  # a backend without gather: every rank raises alike
+                if "gather" not in str(e).lower():
+                    raise
+                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+                parts = None
+            if rank == 0 and parts is not None:
+                for r in range(1, world):
+                    idx, ok = plan[r]
+                    flat[idx[ok]] = parts[r][ok]
+        else:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if reduce_count:
+            cnt = torch.tensor([local], dtype=torch.int64, device=accum.device)
+            dist.reduce(cnt, dst=0, op=dist.ReduceOp.SUM)
+            total = int(cnt.item())
     return total, local

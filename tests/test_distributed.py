@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, sample_shards, out_path):
+def _worker(rank, world, port, sample_shards, use_gather, out_path):
     import sys
 
     sys.path.insert(0, ROOT)
@@ -48,20 +48,21 @@ def _worker(rank, world, port, sample_shards, out_path):
 
         accum = torch.zeros((96, 96, 3), dtype=torch.float64)
         total, local = distributed.render_frame(render_local, accum, rank, world, spp, seed=0, tile_size=16,
-                                                sample_shards=sample_shards, dist=dist)
+                                                sample_shards=sample_shards, dist=dist, opts=s.opts if use_gather else None)
         if rank == 0:
             np.save(out_path, accum.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sample_shards", [1, 2])
-def test_two_rank_gloo_frame_equals_single_rank(libs, tmp_path, sample_shards):
+@pytest.mark.parametrize("sample_shards,use_gather", [(1, True), (1, False), (2, False)])
+def test_two_rank_gloo_frame_equals_single_rank(libs, tmp_path, sample_shards, use_gather):
+    """use_gather: tile shards exchanged as one gather of each rank's own tiles instead of a full-frame reduce."""
     import torch.multiprocessing as mp
 
     _, ob = libs
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(2, _free_port(), sample_shards, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), sample_shards, use_gather, out), nprocs=2, join=True)
     frame = np.load(out)
     s = load_scene("test", size=96)
     full, _, _ = ob.OracleScene(s.desc).render(mode=ob.MODE_CANONICAL, threads=4, want_rgba=False)
