@@ -51,7 +51,7 @@ def main():
                          "3840x2160 64 spp unless --size/--spp say otherwise)")
     ap.add_argument("--spp", type=int, default=0, help="override samples_per_pixel (0 = scene file)")
     ap.add_argument("--size", type=int, default=0, help="override width=height (0 = scene file)")
-    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--tile", type=int, default=8, help="edge of the tiles dealt to ranks (8x8 = one 64-pixel granule: finest, best balanced)")
     ap.add_argument("--sample-shards", type=int, default=1)
     ap.add_argument("--pool-gib", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -175,6 +175,9 @@ struct rt_scene {
     Counters *h_ctr = nullptr;  // pinned
     uint32_t *d_tiles = nullptr;
     uint32_t d_tiles_cap = 0;
+    bool plan_valid = false;  // d_tiles holds the tile list of plan_key
+    rt_render_params plan_key{};
+    WorkList plan_wl{};
     double est_nodes_per_item = 0.0, est_shadows_per_item = 0.0;
 
     ~rt_scene() {
@@ -303,6 +306,32 @@ int plan_tiles(const rt_render_options &o, const rt_render_params *prm, std::vec
 }
 
 int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStream_t stream) {
+    // the tile partition of a call depends on its window / shard fields only: a frame loop
+    // (same params every frame) plans, sorts and uploads its tile list once
+    rt_render_params key{};
+    if (prm) key = *prm;
+    key.seed = 0;
+    key.flags = 0;
+    key.s0 = key.s1 = 0;
+    if (s->plan_valid && std::memcmp(&key, &s->plan_key, sizeof(key)) == 0) {
+        *plan = CallPlan{};
+        plan->wl = s->plan_wl;
+        rt_render_params p{};
+        if (prm) p = *prm;
+        uint32_t s0 = p.s0, s1 = p.s1;
+        if (s1 == 0) {
+            s0 = 0;
+            s1 = s->dev.opts.samples_per_pixel;
+        }
+        if (s0 >= s1 || s1 > s->dev.opts.samples_per_pixel) return fail(RT_ERR_INVALID, "render window / sample range out of range");
+        plan->wl.s0 = s0;
+        plan->wl.ns = s1 - s0;
+        plan->wl.seed = p.seed;
+        plan->total_items = static_cast<uint64_t>(plan->wl.n_tiles) * plan->wl.tile_w * plan->wl.tile_h * plan->wl.ns;
+        if (plan->total_items > 0xFFFFFFFFull) return fail(RT_ERR_INVALID, "more than 2^32 camera rays in one call");
+        return RT_OK;
+    }
+    s->plan_valid = false;
     std::vector<uint32_t> tiles;
     WorkList &wl = plan->wl;
     int prc = plan_tiles(s->dev.opts, prm, &tiles, &wl);
@@ -320,6 +349,9 @@ int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStrea
         HIP_TRY(hipStreamSynchronize(stream));  // `tiles` is a local
     }
     wl.tile_xy = s->d_tiles;
+    s->plan_key = key;
+    s->plan_wl = wl;
+    s->plan_valid = true;
     return RT_OK;
 }
 

@@ -64,6 +64,58 @@ __device__ __forceinline__ uint32_t shard_item(const Shards &sh, uint32_t shard,
     return ((j / sh.granule) * sh.count + shard) * sh.granule + j % sh.granule;
 }
 
+// Work map of one level: the node (or shadow-ray) lists of all shards as ONE list
+// of 64-entry groups, so every block of a launch gets the same share of work
+// whatever the shards hold (a shard that received the expensive pixels of a small
+// batch would otherwise keep its blocks busy long after the others have drained).
+// Shards stay the unit of ALLOCATION (a block bump-allocates from the shard
+// blockIdx.x % count, wherever the parent lives); records are addressed by
+// absolute pool index, so parents and children may sit in different shards.
+struct LevelMap {
+    uint32_t prefix[MAX_SHARDS + 1];  // groups before shard k
+    uint32_t base[MAX_SHARDS];        // pool index of the shard's first entry of this list
+    uint32_t count[MAX_SHARDS];
+    uint32_t dead;                    // some shard overflowed: the batch will be re-run, do nothing
+};
+// All threads of the block call it (one __syncthreads inside); returns the number of groups.
+__device__ __forceinline__ uint32_t level_map_build(LevelMap &m, const Counters *ctrs, const Shards &sh, uint32_t level,
+                                                   bool shadow_list) {
+    if (threadIdx.x < 64u) {
+        const uint32_t k = threadIdx.x;
+        uint32_t cnt = 0, over = 0;
+        if (k < sh.count) {
+            cnt = shadow_list ? static_cast<uint32_t>(ctrs[k].shadow_alloc) : ctrs[k].level_count[level];
+            over = ctrs[k].overflow;
+            m.base[k] = shadow_list ? k * sh.shadow_cap : k * sh.node_cap + ctrs[k].level_start[level];
+            m.count[k] = cnt;
+        }
+        uint32_t x = (cnt + 63u) / 64u;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            if (k >= off) x += y;
+        }
+        if (k < sh.count) m.prefix[k + 1] = x;
+        if (k == 0) {
+            m.prefix[0] = 0;
+        }
+        const unsigned long long any_over = __ballot(over != 0);
+        if (k == 0) m.dead = any_over ? 1u : 0u;
+    }
+    __syncthreads();
+    return m.dead ? 0u : m.prefix[sh.count];
+}
+// group -> (pool index of its first entry, valid entries in it)
+__device__ __forceinline__ uint32_t level_map_group(const LevelMap &m, const Shards &sh, uint32_t group, uint32_t *n_valid) {
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t step = MAX_SHARDS / 2; step >= 1; step >>= 1)
+        if (k + step < sh.count && m.prefix[k + step] <= group) k += step;
+    const uint32_t first = (group - m.prefix[k]) * 64u;
+    *n_valid = min(64u, m.count[k] - first);
+    return m.base[k] + first;
+}
+
 // Wave-aggregated bump allocation: every lane of the wave must call it.
 __device__ __forceinline__ uint64_t wave_alloc(unsigned long long *counter, uint32_t n, uint32_t *wave_total) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -376,13 +428,14 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
                                                         uint32_t level) {
     extern __shared__ uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;
-    const ShardCtx c = shard_ctx(ctrs, shards);
-    Counters *ctr = c.ctr;
-    if (ctr->overflow) return;
-    const uint32_t start = c.node_off + ctr->level_start[level], count = ctr->level_count[level];
+    __shared__ LevelMap map;
+    Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
+    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
     unsigned long long n_nodes = 0, n_prims = 0;
-    for (uint32_t i = c.bid * BLOCK + threadIdx.x; i < count; i += c.nblocks * BLOCK) {
-        const uint32_t idx = start + i;
+    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
+        uint32_t n_valid;
+        const uint32_t idx = level_map_group(map, shards, g, &n_valid) + (threadIdx.x & 63u);
+        if ((threadIdx.x & 63u) >= n_valid) continue;
         const uint32_t meta = np.meta[idx];
         if (meta & META_INACTIVE) {
             np.prim[idx] = RT_NO_HIT;
@@ -496,13 +549,20 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
                                                        Shards shards, uint32_t probe_count) {
     extern __shared__ uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;
-    const ShardCtx c = shard_ctx(ctrs, shards);
-    Counters *ctr = c.ctr;
-    if (ctr->overflow) return;
-    const uint32_t count = PROBE ? probe_count : static_cast<uint32_t>(ctr->shadow_alloc);
+    __shared__ LevelMap map;
+    Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
+    const uint32_t n_groups = PROBE ? (probe_count + 63u) / 64u : level_map_build(map, ctrs, shards, 0u, true);
     unsigned long long n_nodes = 0, n_prims = 0;
-    for (uint32_t i0 = c.bid * BLOCK + threadIdx.x; i0 < count; i0 += c.nblocks * BLOCK) {
-        const uint32_t i = (PROBE ? c.node_off : c.shadow_off) + i0;
+    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
+        uint32_t n_valid, i;
+        if (PROBE) {  // single-shard launch: rays 0..probe_count of the node pool
+            i = g * 64u;
+            n_valid = min(64u, probe_count - i);
+        } else {
+            i = level_map_group(map, shards, g, &n_valid);
+        }
+        i += threadIdx.x & 63u;
+        if ((threadIdx.x & 63u) >= n_valid) continue;
         RayD ray;
         double tmax;
         if (PROBE) {
@@ -580,19 +640,20 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
 struct WaveQueue {
     uint32_t *q;   // 128 entries of this wave
     uint32_t n;    // wave-uniform fill
-    uint32_t base; // next node (level-relative) this wave scans
+    uint32_t base; // next 64-node group of the level's work map this wave scans
 };
 __device__ __forceinline__ void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-// Scans until 64 live nodes are queued or the wave's share of [0,count) is
-// exhausted; returns how many to process now (0 = finished).
-__device__ __forceinline__ uint32_t queue_fill(WaveQueue &wq, const uint32_t *__restrict__ meta, uint32_t start, uint32_t count,
-                                              uint32_t stride, uint32_t lane) {
-    while (wq.n < 64u && wq.base < count) {
-        const uint32_t i = wq.base + lane;
-        const bool live = i < count && !(meta[start + i] & (META_INACTIVE | META_DONE));
+// Scans until 64 live nodes are queued or the wave's share of the level's groups
+// is exhausted; returns how many to process now (0 = finished).
+__device__ __forceinline__ uint32_t queue_fill(WaveQueue &wq, const uint32_t *__restrict__ meta, const LevelMap &map,
+                                              const Shards &shards, uint32_t n_groups, uint32_t stride, uint32_t lane) {
+    while (wq.n < 64u && wq.base < n_groups) {
+        uint32_t n_valid;
+        const uint32_t idx = level_map_group(map, shards, wq.base, &n_valid) + lane;
+        const bool live = lane < n_valid && !(meta[idx] & (META_INACTIVE | META_DONE));
         const unsigned long long mask = __ballot(live);
-        if (live) wq.q[wq.n + __popcll(mask & ((1ull << lane) - 1ull))] = start + i;
+        if (live) wq.q[wq.n + __popcll(mask & ((1ull << lane) - 1ull))] = idx;
         wq.n += static_cast<uint32_t>(__popcll(mask));
         wq.base += stride;
     }
@@ -638,21 +699,21 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
                                                  Shards shards, uint32_t level) {
     __shared__ ExpandLds L;
     __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
-    const ShardCtx c = shard_ctx(ctrs, shards);
+    __shared__ LevelMap map;
+    const ShardCtx c = shard_ctx(ctrs, shards);  // the shard this block ALLOCATES children and shadow rays from
     Counters *ctr = c.ctr;
-    if (ctr->overflow) return;
-    const uint32_t start = c.node_off + ctr->level_start[level], count = ctr->level_count[level];
+    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
     const bool next_real = level + 1 < sc.opts.max_depth;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
     const uint32_t child_depth = level + 1;
     WaveQueue wq;
     wq.q = queue_lds + (tid >> 6) * 128u;
     wq.n = 0;
-    wq.base = (c.bid * (BLOCK / 64) + (tid >> 6)) * 64u;
-    const uint32_t wave_stride = c.nblocks * BLOCK;
-    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, start, count, wave_stride, lane)) != 0; queue_pop(wq, n_proc, lane)) {
+    wq.base = blockIdx.x * (BLOCK / 64) + (tid >> 6);
+    const uint32_t wave_stride = gridDim.x * (BLOCK / 64);
+    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, map, shards, n_groups, wave_stride, lane)) != 0; queue_pop(wq, n_proc, lane)) {
         const bool valid = lane < n_proc;
-        const uint32_t idx = valid ? wq.q[lane] : start;
+        const uint32_t idx = valid ? wq.q[lane] : 0u;
         uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0, phong_flag = 0;
         uint32_t prim = RT_NO_HIT, meta = 0;
         if (valid) {
@@ -847,18 +908,16 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
 __global__ __launch_bounds__(BLOCK, RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
                                                   uint32_t level) {
     __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
-    const ShardCtx c = shard_ctx(ctrs, shards);
-    Counters *ctr = c.ctr;
-    if (ctr->overflow) return;
-    const uint32_t start = c.node_off + ctr->level_start[level], count = ctr->level_count[level];
+    __shared__ LevelMap map;
+    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
     const bool next_real = level + 1 < sc.opts.max_depth;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     WaveQueue wq;
     wq.q = queue_lds + (tid >> 6) * 128u;
     wq.n = 0;
-    wq.base = (c.bid * (BLOCK / 64) + (tid >> 6)) * 64u;
-    const uint32_t wave_stride = c.nblocks * BLOCK;
-    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, start, count, wave_stride, lane)) != 0; queue_pop(wq, n_proc, lane)) {
+    wq.base = blockIdx.x * (BLOCK / 64) + (tid >> 6);
+    const uint32_t wave_stride = gridDim.x * (BLOCK / 64);
+    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, map, shards, n_groups, wave_stride, lane)) != 0; queue_pop(wq, n_proc, lane)) {
         if (lane >= n_proc) continue;
         const uint32_t idx = wq.q[lane];
         const uint32_t meta = np.meta[idx];
