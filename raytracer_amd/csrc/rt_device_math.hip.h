@@ -124,8 +124,10 @@ __device__ __forceinline__ d3 sample_cosine_hemisphere(d3 w, double u1, double u
             r = ry;
             theta = HALF_PI - QUARTER_PI * (rx / ry);
         }
-        px = r * cos(theta);
-        py = r * sin(theta);
+        double st, ct;
+        sincos(theta, &st, &ct);  // one argument reduction for both
+        px = r * ct;
+        py = r * st;
     }
     double pz = sqrt(1.0 - px * px - py * py);
     d3 u = fabs(w.x) > F64_EPS ? cross3(w, mk3(0.0, 1.0, 0.0)) : cross3(w, mk3(1.0, 0.0, 0.0));
@@ -138,15 +140,17 @@ __device__ __forceinline__ d3 sample_cone(d3 w, double max_angle, double u1, dou
     if (max_angle < F64_EPS) return w;
     double theta = acos(u1);
     theta = theta * max_angle / HALF_PI;
-    double z = cos(theta);
-    double radius = sin(theta);
+    double z, radius;
+    sincos(theta, &radius, &z);
     double phi = u2 * TWO_PI;
+    double sp, cp;
+    sincos(phi, &sp, &cp);
     d3 u = cross3(w, mk3(0.0, 0.0, 1.0));
     double mag = length3(u);
-    if (mag < F64_EPS) return unit3(mk3(radius * cos(phi), radius * sin(phi), rsign(w.z) * z));
+    if (mag < F64_EPS) return unit3(mk3(radius * cp, radius * sp, rsign(w.z) * z));
     u = unit3(u);
     d3 v = unit3(cross3(w, u));
-    return unit3(u * radius * cos(phi) + v * radius * sin(phi) + w * z);
+    return unit3(u * radius * cp + v * radius * sp + w * z);
 }
 
 // src/utils/rays.rs

@@ -511,12 +511,15 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
                     }
                 }
             }
-            if (done) {
+            if (done) {  // resolved word: bit 0 = occluded, bit 1 = RGB is not all zero (only then is it stored / read)
                 np.meta[idx] = meta | META_DONE;
+                if (rgb.x != 0.0 || rgb.y != 0.0 || rgb.z != 0.0) {
+                    flag |= 2u;
+                    np.t[idx] = rgb.x;
+                    np.bu[idx] = rgb.y;
+                    np.bv[idx] = rgb.z;
+                }
                 np.prim[idx] = flag;
-                np.t[idx] = rgb.x;
-                np.bu[idx] = rgb.y;
-                np.bv[idx] = rgb.z;
                 continue;
             }
         }
@@ -937,7 +940,8 @@ __global__ __launch_bounds__(BLOCK, RESOLVE_WAVES) void k_resolve(SceneDev sc, N
             const uint32_t counts = np.counts[idx];
             const uint32_t nT = (counts >> 16) & 1u;
             uint32_t child = np.first_child[idx];
-            auto child_rgb = [&](uint32_t at) { return mk3(np.t[at], np.bu[at], np.bv[at]); };
+            // a resolved child: word bit 1 says whether its RGB is non-zero (4 of 5 are black: one load instead of four)
+            auto child_rgb = [&](uint32_t at) { return (np.prim[at] & 2u) ? mk3(np.t[at], np.bu[at], np.bv[at]) : mk3(0.0, 0.0, 0.0); };
 
             if (illum) {
                 // get_emissive_phong :135-167 / get_emissive_physical :263-337
@@ -1070,8 +1074,9 @@ __global__ __launch_bounds__(BLOCK, RESOLVE_WAVES) void k_resolve(SceneDev sc, N
                 if (next_real) {
                     unoccluded = 0;
                     for (uint32_t g = 0; g < nG; ++g) {
-                        incoming = incoming + child_rgb(child + g);
-                        if (np.prim[child + g] == 0u) unoccluded++;
+                        const uint32_t w = np.prim[child + g];
+                        if (w & 2u) incoming = incoming + mk3(np.t[child + g], np.bu[child + g], np.bv[child + g]);  // + 0.0 is exact
+                        if (!(w & 1u)) unoccluded++;
                     }
                 }
                 incoming = incoming / static_cast<double>(nG);
@@ -1087,9 +1092,12 @@ __global__ __launch_bounds__(BLOCK, RESOLVE_WAVES) void k_resolve(SceneDev sc, N
                 result = sat01(color);                                                                  // :543
             }
         }
-        np.t[idx] = result.x;
-        np.bu[idx] = result.y;
-        np.bv[idx] = result.z;
+        if (!(result.x == 0.0 && result.y == 0.0 && result.z == 0.0)) {  // NaN counts as non-zero
+            flag |= 2u;
+            np.t[idx] = result.x;
+            np.bu[idx] = result.y;
+            np.bv[idx] = result.z;
+        }
         np.prim[idx] = flag;
     }
 }
@@ -1107,8 +1115,9 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(SceneDev sc, WorkList wl, 
         if (np.meta[node0] & META_INACTIVE) continue;
         uint32_t px, py, sample;
         item_to_pixel(wl, np.root[node0], &px, &py, &sample);
-        d3 sum = mk3(np.t[node0], np.bu[node0], np.bv[node0]);
-        for (uint32_t s = 1; s < wl.ns; ++s) sum = sum + mk3(np.t[node0 + s], np.bu[node0 + s], np.bv[node0 + s]);
+        d3 sum = mk3(0.0, 0.0, 0.0);
+        for (uint32_t s = 0; s < wl.ns; ++s)
+            if (np.prim[node0 + s] & 2u) sum = sum + mk3(np.t[node0 + s], np.bu[node0 + s], np.bv[node0 + s]);
         const uint64_t at = (static_cast<uint64_t>(py) * sc.opts.width + px) * 3ull;
         accum[at] += sum.x;
         accum[at + 1] += sum.y;
