@@ -761,11 +761,19 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
             c.wave_node_steps += ck.wave_node_steps;
             c.wave_leaf_rounds += ck.wave_leaf_rounds;
             c.wave_iterations += ck.wave_iterations;
+            for (uint32_t q = 0; q < 16; ++q) c.leaf_census[q] += ck.leaf_census[q];
+            for (uint32_t q = 0; q < 4; ++q) c.leaf_lanes[q] += ck.leaf_lanes[q];
             c.wave_max_steps = std::max(c.wave_max_steps, ck.wave_max_steps);
         }
         if (count_work && std::getenv("MI355RT_CENSUS"))
             std::fprintf(stderr, "[mi355rt census] closest kernel, wave level: %llu node visits, %llu leaf rounds over %llu waves (all levels); busiest wave %llu node visits\n",
                          c.wave_node_steps, c.wave_leaf_rounds, c.wave_iterations, c.wave_max_steps);
+        if (count_work && std::getenv("MI355RT_CENSUS")) {
+            std::fprintf(stderr, "[mi355rt census] leaf rounds by content (T S C X=exact box):");
+            for (uint32_t q = 0; q < 16; ++q)
+                if (c.leaf_census[q]) std::fprintf(stderr, " %s%s%s%s=%llu", q & 1 ? "T" : "", q & 2 ? "S" : "", q & 4 ? "C" : "", q & 8 ? "X" : "", c.leaf_census[q]);
+            std::fprintf(stderr, "\n[mi355rt census] leaf-round lanes %llu, exact-box lanes %llu, hit lanes %llu\n", c.leaf_lanes[0], c.leaf_lanes[1], c.leaf_lanes[2]);
+        }
         if (count_work && std::getenv("MI355RT_CENSUS"))
             for (uint32_t l = 0; l < max_depth && l < MAX_LEVELS; ++l)
                 std::fprintf(stderr, "[mi355rt census] level %u: colour %llu illum %llu miss %llu no-emit %llu\n", l, c.census[l][0],

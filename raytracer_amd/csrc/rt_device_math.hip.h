@@ -201,16 +201,23 @@ __device__ __forceinline__ bool prim_box_test(const double *__restrict__ center,
     return true;
 }
 
-// Sufficient condition for prim_box_test to pass, without its six divisions:
-// the point o + t d of an accepted primitive hit (t >= 0, t <= max_distance for
-// shadow rays) lies inside the box with a margin of 1e-9 relative on every axis.
-// Then on every axis (near plane - o)/d < t < (far plane - o)/d holds by a margin
-// that exceeds the rounding of the reference-order slab arithmetic (a few ulps) a
-// million times, so none of its rejections can fire (d = +-0: the quotients are
-// -inf / +inf).  Flat boxes (half = 0 on an axis) and hits on a box face never
-// qualify and take the exact test.
+// Sufficient condition for prim_box_test to pass, without its six divisions: some
+// point o + t d of the ray with t >= 0 (and t <= max_distance for shadow rays) lies
+// inside the box with a margin of 1e-9 relative on every axis.  Then on every axis
+// (near plane - o)/d < t < (far plane - o)/d holds by a margin that exceeds the
+// rounding of the reference-order slab arithmetic (a few ulps) a million times
+// (d = +-0: the quotients are -inf / +inf), so: no pair of slabs is disjoint
+// (every near < t < every far), d_far > t >= 0 rules out "both negative", and
+// d_near < t <= max_distance rules out the distance rejection.
+// The caller picks t (`t_probe` of hit_bounded): the hit itself for a triangle, the
+// middle of the ray's chord through a sphere or cube clipped to t >= 0 -- a hit ON
+// a face of an axis-aligned cube lies on the face of its box, where no margin
+// exists, but the chord's midpoint is interior.  The test checks the point it is
+// given, so a grazing chord or a flat box (half = 0 on an axis) simply fails it and
+// takes the exact test.
 __device__ __forceinline__ bool prim_box_surely_passes(const double *__restrict__ center, const double *__restrict__ half,
-                                                       const RayD &r, double t) {
+                                                       const RayD &r, double t, bool has_max, double max_distance) {
+    if (!(t >= 0.0) || (has_max && !(t <= max_distance))) return false;
     const double px = r.o.x + r.d.x * t, py = r.o.y + r.d.y * t, pz = r.o.z + r.d.z * t;
     const double ex = 1e-9 * (fabs(r.o.x) + fabs(center[0]) + half[0]);
     const double ey = 1e-9 * (fabs(r.o.y) + fabs(center[1]) + half[1]);
@@ -225,80 +232,6 @@ struct HitRec {
 
 // side rule shared by sphere / cube: Both or shadow ray -> two-sided
 __device__ __forceinline__ bool is_two_sided(uint32_t side, bool shadow) { return side == RT_SIDE_BOTH || shadow; }
-
-__device__ __forceinline__ bool hit_sphere(double radius, uint32_t side, bool shadow, const RayD &r, bool has_max,
-                                           double max_distance, HitRec *h) {
-    double ray_proj = dot3(r.o, r.d);
-    double a = dot3(r.d, r.d);
-    double b = 2.0 * ray_proj;
-    double c = dot3(r.o, r.o) - radius * radius;
-    double disc = b * b - 4.0 * a * c;
-    if (disc < 0.0) return false;
-    double t0, t1;
-    if (disc == 0.0) {
-        t0 = -0.5 * b / a;
-        t1 = t0;
-    } else {
-        double q = -0.5 * (b + rsign(b) * sqrt(disc));
-        double r0 = q / a, r1 = c / q;
-        t0 = fmin(r0, r1);
-        t1 = fmax(r0, r1);
-    }
-    double dist;
-    if (is_two_sided(side, shadow)) dist = t0 < 0.0 ? t1 : t0;
-    else if (side == RT_SIDE_FRONT) dist = t0;
-    else dist = t1;
-    if (dist < 0.0 || (has_max && max_distance < dist)) return false;
-    h->t = dist;
-    h->bu = 0.0;
-    h->bv = 0.0;
-    return true;
-}
-
-__device__ __forceinline__ bool hit_cube(double size, uint32_t side, bool shadow, const RayD &r, bool has_max,
-                                         double max_distance, HitRec *h) {
-    double sx = rsign(r.d.x), sy = rsign(r.d.y), sz = rsign(r.d.z);
-    double half = size / 2.0;
-    int near_axis = 0, far_axis = 0;
-    bool near_pos = sx < 0.0, far_pos = sx > 0.0;
-    double d_near = (-r.o.x - sx * half) / r.d.x;
-    double d_far = (-r.o.x + sx * half) / r.d.x;
-    double dy_near = (-r.o.y - sy * half) / r.d.y;
-    double dy_far = (-r.o.y + sy * half) / r.d.y;
-    if (dy_far < d_near || d_far < dy_near) return false;
-    if (dy_near > d_near) {
-        near_axis = 1;
-        near_pos = sy < 0.0;
-        d_near = dy_near;
-    }
-    if (d_far > dy_far) {
-        far_axis = 1;
-        far_pos = sy > 0.0;
-        d_far = dy_far;
-    }
-    double dz_near = (-r.o.z - sz * half) / r.d.z;
-    double dz_far = (-r.o.z + sz * half) / r.d.z;
-    if (dz_far < d_near || d_far < dz_near) return false;
-    if (dz_near > d_near) {
-        near_axis = 2;
-        near_pos = sz < 0.0;
-        d_near = dz_near;
-    }
-    if (d_far > dz_far) {
-        far_axis = 2;
-        far_pos = sz > 0.0;
-        d_far = dz_far;
-    }
-    bool use_near = is_two_sided(side, shadow) ? !(d_near < 0.0) : (side == RT_SIDE_FRONT);
-    double dist = use_near ? d_near : d_far;
-    int axis = use_near ? near_axis : far_axis;
-    bool positive = use_near ? near_pos : far_pos;
-    if (dist < 0.0 || (has_max && max_distance < dist)) return false;
-    h->t = dist;
-    h->bu = static_cast<double>(axis + (positive ? 4 : 0));
-    h->bv = 0.0;
-    return true;
-}
 
 __device__ __forceinline__ bool hit_plane(d3 normal, uint32_t side, bool shadow, const RayD &r, bool has_max,
                                           double max_distance, HitRec *h) {
@@ -316,29 +249,134 @@ __device__ __forceinline__ bool hit_plane(d3 normal, uint32_t side, bool shadow,
     return true;
 }
 
-__device__ __forceinline__ bool hit_triangle(const double *__restrict__ g, uint32_t side, bool shadow, const RayD &r,
-                                             bool has_max, double max_distance, HitRec *h) {
-    d3 p0 = mk3(g[0], g[1], g[2]);
-    d3 e1 = mk3(g[3], g[4], g[5]);  // p1 - p0, p2 - p0: precomputed on the host (same f64 subtraction)
-    d3 e2 = mk3(g[6], g[7], g[8]);
-    d3 pv = cross3(r.d, e2);
-    double det = dot3(e1, pv);
-    bool reject;
-    if (is_two_sided(side, shadow)) reject = fabs(det) < F64_EPS;
-    else if (side == RT_SIDE_FRONT) reject = det < F64_EPS;
-    else reject = -det < F64_EPS;
-    if (reject) return false;
-    d3 tv = r.o - p0;
-    double u = dot3(tv, pv) / det;
-    if (!(u >= 0.0 && u <= 1.0)) return false;
-    d3 qv = cross3(tv, e1);
-    double v = dot3(r.d, qv) / det;
-    if (v < 0.0 || 1.0 < u + v) return false;
-    double dist = dot3(e2, qv) / det;
-    if (dist < 0.0 || (has_max && max_distance < dist)) return false;
+// The three bounded-primitive tests as ONE routine whose f64 divisions sit in a
+// block every lane of the wave reaches together.  A wave's lanes hold leaves of
+// different types; evaluated as three separate routines the wave pays the
+// triangle's 3 divisions, the sphere's 2 and the cube's 6 one after the other
+// (11 division sequences, the dominant cost of a leaf round).  Here each type
+// first forms its (numerator, denominator) pairs, the wave divides once (3
+// quotients; the cube's other 3 in a second block only cubes enter), then each
+// type takes its decisions.  Every quotient is the IEEE division of the operands
+// the reference divides (triangle.rs:193-232 Moeller-Trumbore with the edges
+// precomputed on the host by the same f64 subtraction; sphere.rs:101-130 with
+// utils/mod.rs:35-47 `quadratic`; cube.rs:100-174) and every decision the same
+// comparison; only the early exits between a type's divisions are gone (they are
+// pure predicates, so evaluating the later ones too changes nothing).
+// *t_probe: a ray parameter inside the primitive, for prim_box_surely_passes.
+template <bool SHADOW>
+__device__ __forceinline__ bool hit_bounded(const double *__restrict__ g, uint32_t type, uint32_t side, const RayD &r,
+                                            double max_distance, HitRec *h, double *t_probe) {
+    double n1 = 0.0, n2 = 0.0, n3 = 0.0, q_d1 = 1.0, q_d2 = 1.0, q_d3 = 1.0;
+    double sx = 0.0, sy = 0.0, sz = 0.0, half = 0.0;  // cube
+    bool one_root = false;                            // sphere, disc == 0
+    if (type == RT_PRIM_TRIANGLE) {
+        const d3 p0 = mk3(g[0], g[1], g[2]), e1 = mk3(g[3], g[4], g[5]), e2 = mk3(g[6], g[7], g[8]);
+        const d3 pv = cross3(r.d, e2);
+        const double det = dot3(e1, pv);
+        bool reject;
+        if (is_two_sided(side, SHADOW)) reject = fabs(det) < F64_EPS;
+        else if (side == RT_SIDE_FRONT) reject = det < F64_EPS;
+        else reject = -det < F64_EPS;
+        if (reject) return false;
+        const d3 tv = r.o - p0;
+        const d3 qv = cross3(tv, e1);
+        n1 = dot3(tv, pv);
+        n2 = dot3(r.d, qv);
+        n3 = dot3(e2, qv);
+        q_d1 = q_d2 = q_d3 = det;
+    } else if (type == RT_PRIM_SPHERE) {
+        const double radius = g[0];
+        const double ray_proj = dot3(r.o, r.d);
+        const double a = dot3(r.d, r.d);
+        const double b = 2.0 * ray_proj;
+        const double c = dot3(r.o, r.o) - radius * radius;
+        const double disc = b * b - 4.0 * a * c;
+        if (disc < 0.0) return false;
+        if (disc == 0.0) {
+            one_root = true;
+            n1 = -0.5 * b;
+            q_d1 = a;
+        } else {
+            const double q = -0.5 * (b + rsign(b) * sqrt(disc));
+            n1 = q;
+            q_d1 = a;
+            n2 = c;
+            q_d2 = q;
+        }
+    } else {
+        sx = rsign(r.d.x);
+        sy = rsign(r.d.y);
+        sz = rsign(r.d.z);
+        half = g[0] / 2.0;
+        n1 = -r.o.x - sx * half;
+        n2 = -r.o.x + sx * half;
+        n3 = -r.o.y - sy * half;
+        q_d1 = q_d2 = r.d.x;
+        q_d3 = r.d.y;
+    }
+    const double q1 = n1 / q_d1, q2 = n2 / q_d2, q3 = n3 / q_d3;
+    if (type == RT_PRIM_TRIANGLE) {
+        const double u = q1, v = q2, dist = q3;
+        if (!(u >= 0.0 && u <= 1.0)) return false;
+        if (v < 0.0 || 1.0 < u + v) return false;
+        if (dist < 0.0 || (SHADOW && max_distance < dist)) return false;
+        h->t = dist;
+        h->bu = u;
+        h->bv = v;
+        *t_probe = dist;
+        return true;
+    }
+    if (type == RT_PRIM_SPHERE) {
+        const double t0 = one_root ? q1 : fmin(q1, q2), t1 = one_root ? q1 : fmax(q1, q2);
+        double dist;
+        if (is_two_sided(side, SHADOW)) dist = t0 < 0.0 ? t1 : t0;
+        else if (side == RT_SIDE_FRONT) dist = t0;
+        else dist = t1;
+        if (dist < 0.0 || (SHADOW && max_distance < dist)) return false;
+        h->t = dist;
+        h->bu = 0.0;
+        h->bv = 0.0;
+        *t_probe = 0.5 * (fmax(t0, 0.0) + t1);
+        return true;
+    }
+    int near_axis = 0, far_axis = 0;
+    bool near_pos = sx < 0.0, far_pos = sx > 0.0;
+    double d_near = q1, d_far = q2;
+    const double dy_near = q3;
+    const double dy_far = (-r.o.y + sy * half) / r.d.y;
+    const double dz_near = (-r.o.z - sz * half) / r.d.z;
+    const double dz_far = (-r.o.z + sz * half) / r.d.z;
+    if (dy_far < d_near || d_far < dy_near) return false;
+    if (dy_near > d_near) {
+        near_axis = 1;
+        near_pos = sy < 0.0;
+        d_near = dy_near;
+    }
+    if (d_far > dy_far) {
+        far_axis = 1;
+        far_pos = sy > 0.0;
+        d_far = dy_far;
+    }
+    if (dz_far < d_near || d_far < dz_near) return false;
+    if (dz_near > d_near) {
+        near_axis = 2;
+        near_pos = sz < 0.0;
+        d_near = dz_near;
+    }
+    if (d_far > dz_far) {
+        far_axis = 2;
+        far_pos = sz > 0.0;
+        d_far = dz_far;
+    }
+    const bool use_near = is_two_sided(side, SHADOW) ? !(d_near < 0.0) : (side == RT_SIDE_FRONT);
+    const double dist = use_near ? d_near : d_far;
+    const int axis = use_near ? near_axis : far_axis;
+    const bool positive = use_near ? near_pos : far_pos;
+    if (dist < 0.0 || (SHADOW && max_distance < dist)) return false;
     h->t = dist;
-    h->bu = u;
-    h->bv = v;
+    h->bu = static_cast<double>(axis + (positive ? 4 : 0));
+    h->bv = 0.0;
+    *t_probe = 0.5 * (fmax(d_near, 0.0) + d_far);
     return true;
 }
 

@@ -180,6 +180,9 @@ struct Counters {
     unsigned long long census[MAX_LEVELS][4];
     // RT_FLAG_COUNT_WORK, closest-hit kernel, wave level: node visits, leaf rounds, waves that ran, node visits of the busiest wave
     unsigned long long wave_node_steps, wave_leaf_rounds, wave_iterations, wave_max_steps;
+    // leaf rounds of the closest-hit kernel by what the wave held: bit 0 triangles, bit 1 spheres, bit 2 cubes, bit 3 some lane took the exact box test
+    unsigned long long leaf_census[16];
+    unsigned long long leaf_lanes[4];  // lanes in leaf rounds, lanes taking the exact box test, lanes whose primitive was hit
 };
 
 // The wavefront pools are split into `count` shards.  A shard is an independent

@@ -261,6 +261,8 @@ __global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
     for (uint32_t l = 0; l < MAX_LEVELS; ++l)
         for (uint32_t q = 0; q < 4; ++q) ctr->census[l][q] = 0;
     ctr->wave_node_steps = ctr->wave_leaf_rounds = ctr->wave_iterations = ctr->wave_max_steps = 0;
+    for (uint32_t q = 0; q < 16; ++q) ctr->leaf_census[q] = 0;
+    for (uint32_t q = 0; q < 4; ++q) ctr->leaf_lanes[q] = 0;
 }
 
 __global__ void k_advance_level(Counters *ctrs, Shards sh, uint32_t level) {
@@ -360,7 +362,7 @@ struct ObjRayCache {
 
 template <bool SHADOW>
 __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPrim *__restrict__ lp, const RayD &ray,
-                                               ObjRayCache &cache, double max_distance, HitRec *h) {
+                                               ObjRayCache &cache, double max_distance, HitRec *h, uint32_t *exact_box = nullptr) {
     const uint32_t meta = lp->meta;
     const uint32_t xf = meta >> 4;
     if (xf != cache.xf) {  // Ray::transform (ray_intersection.rs:33-43), shared by a mesh's faces
@@ -370,16 +372,14 @@ __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPri
         cache.xf = xf;
     }
     const uint32_t type = meta & 3u, side = (meta >> 2) & 3u;
-    bool hit;
-    if (type == RT_PRIM_TRIANGLE) hit = hit_triangle(lp->geom, side, SHADOW, cache.r, SHADOW, max_distance, h);
-    else if (type == RT_PRIM_SPHERE) hit = hit_sphere(lp->geom[0], side, SHADOW, cache.r, SHADOW, max_distance, h);
-    else hit = hit_cube(lp->geom[0], side, SHADOW, cache.r, SHADOW, max_distance, h);
-    if (!hit) return false;
+    double t_probe;
+    if (!hit_bounded<SHADOW>(lp->geom, type, side, cache.r, max_distance, h, &t_probe)) return false;
     // centre / half-extent: three 16-byte loads (the kernels are bound by vector-memory instruction issue)
     const double2 *q = reinterpret_cast<const double2 *>(lp);
     const double2 q0 = q[0], q1 = q[1], q2 = q[2];
     const double center[3] = {q0.x, q0.y, q1.x}, half[3] = {q1.y, q2.x, q2.y};
-    if (prim_box_surely_passes(center, half, ray, h->t)) return true;
+    if (prim_box_surely_passes(center, half, ray, t_probe, SHADOW, max_distance)) return true;
+    if (exact_box) *exact_box = 1u;
     return prim_box_test(center, half, ray, SHADOW, max_distance);
 }
 
@@ -481,7 +481,20 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
                     const LeafPrim *lp = sc.leaf_prims + first + k;
                     HitRec h;
                     if (COUNT) n_prims++;
-                    if (test_leaf_prim<false>(sc, lp, ray, cache, 0.0, &h)) {
+                    uint32_t exact_box = 0;
+                    const bool leaf_hit = test_leaf_prim<false>(sc, lp, ray, cache, 0.0, &h, COUNT ? &exact_box : nullptr);
+                    if (COUNT) {  // census of the wave's leaf round: which primitive types are present, how many lanes, exact box tests
+                        const uint32_t ty = lp->meta & 3u;
+                        const unsigned long long m_all = __ballot(true), m_t = __ballot(ty == RT_PRIM_TRIANGLE), m_s = __ballot(ty == RT_PRIM_SPHERE),
+                                                 m_c = __ballot(ty == RT_PRIM_CUBE), m_x = __ballot(exact_box != 0), m_h = __ballot(leaf_hit);
+                        if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(m_all) - 1)) {
+                            atomicAdd(&ctr->leaf_census[(m_t ? 1 : 0) | (m_s ? 2 : 0) | (m_c ? 4 : 0) | (m_x ? 8 : 0)], 1ull);
+                            atomicAdd(&ctr->leaf_lanes[0], static_cast<unsigned long long>(__popcll(m_all)));
+                            atomicAdd(&ctr->leaf_lanes[1], static_cast<unsigned long long>(__popcll(m_x)));
+                            atomicAdd(&ctr->leaf_lanes[2], static_cast<unsigned long long>(__popcll(m_h)));
+                        }
+                    }
+                    if (leaf_hit) {
                         const uint32_t pid = lp->prim_id;
                         bool better = best_id == RT_NO_HIT || h.t < best_t || (h.t == best_t && best_bounded && pid < best_id);
                         if (better) {
