@@ -382,9 +382,10 @@ Shards plan_shards(const rt_scene *s, uint64_t n, uint32_t ns) {
 }
 
 // dynamic LDS of the traversal kernels: per-lane stack of (max leaf depth + 2) entries (sentinel included)
+uint32_t stack_entries(const rt_scene *s) { return static_cast<uint32_t>(s->bvh_depth + 2); }
 uint32_t stack_lds_bytes(const rt_scene *s) {
     static const uint32_t extra = std::getenv("MI355RT_EXTRA_LDS") ? std::atoi(std::getenv("MI355RT_EXTRA_LDS")) : 0;  // occupancy experiments
-    return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + extra;
+    return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + s->dev.n_top_nodes * static_cast<uint32_t>(sizeof(BvhNode)) + extra;
 }
 
 Shards single_shard(const rt_scene *s) { return Shards{1u, s->np.capacity, s->sp.capacity, 1u}; }
@@ -555,6 +556,13 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     for (int k = 0; k < 9; ++k) dev.cam_to_world[k] = d->camera.cam_to_world[k];
     dev.fov_scale = std::tan(d->camera.fov_deg * (3.14159265358979323846 / 180.0) / 2.0);  // :82-84
     dev.root_ref = bvh.root_ref;
+    {   // top of the tree kept in LDS by the traversal kernels: as many nodes as fit next to the per-lane stacks
+        // without costing a block per CU (four 256-thread blocks share 160 KB), at most 512 (16 KB)
+        const uint32_t stack_bytes = (bvh.max_depth + 2u) * BLOCK * static_cast<uint32_t>(sizeof(uint32_t));
+        const uint32_t budget = 40u * 1024u - 1024u;  // per block; 1 KB for the kernels' static LDS
+        const uint32_t fit = stack_bytes < budget ? (budget - stack_bytes) / static_cast<uint32_t>(sizeof(BvhNode)) : 0u;
+        dev.n_top_nodes = static_cast<uint32_t>(std::min<size_t>(bvh.nodes.size(), std::min(fit, 512u)));
+    }
     dev.n_planes = static_cast<uint32_t>(planes.size());
     dev.n_bounded = static_cast<uint32_t>(bounded_ids.size());
     dev.n_prims = d->n_prims;
@@ -701,7 +709,9 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
         if (n == 0) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's samples");
         const uint32_t n32 = static_cast<uint32_t>(n), i0 = static_cast<uint32_t>(item0);
         const Shards sh = plan_shards(s, n, wl.ns);
-        const uint32_t g_level = shard_grid(s, sh, static_cast<uint64_t>(s->n_cus) * 4u * BLOCK, 4);
+        // traversal: 48 blocks per CU, four resident -- the hardware deals out the rest as blocks finish, which evens out
+        // rays of very different cost (4 persistent blocks per CU: scene.json +7 %, the 1M-triangle scene +37 %)
+        const uint32_t g_level = shard_grid(s, sh, static_cast<uint64_t>(s->n_cus) * 48u * BLOCK, 48);
         const uint32_t g_wide = shard_grid(s, sh, static_cast<uint64_t>(gmax) * BLOCK, 8);
 
         timer.begin(CLS_MISC);
@@ -712,10 +722,10 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
         timer.end();
         if (max_depth > 0) {
             for (uint32_t level = 0; level < max_depth; ++level) {
-                const uint32_t g = level == 0 ? shard_grid(s, sh, n, 4) : g_level;
+                const uint32_t g = level == 0 ? shard_grid(s, sh, n, 48) : g_level;
                 timer.begin(CLS_CLOSEST);
-                if (count_work) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level);
-                else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level);
+                if (count_work) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level, stack_entries(s));
+                else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level, stack_entries(s));
                 timer.end();
                 timer.begin(CLS_EXPAND);
                 const uint32_t ge = level == 0 ? shard_grid(s, sh, n, 8) : g_wide;
@@ -726,14 +736,15 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
             }
             timer.begin(CLS_SHADOW);
             if (count_work)
-                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, s->d_ctr, sh, 0u);
+                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, s->d_ctr, sh, 0u, stack_entries(s));
             else
-                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, s->d_ctr, sh, 0u);
+                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, s->d_ctr, sh, 0u, stack_entries(s));
             timer.end();
             for (uint32_t level = max_depth; level-- > 0;) {
                 timer.begin(CLS_RESOLVE);
-                hipLaunchKernelGGL(k_resolve, dim3(level == 0 ? shard_grid(s, sh, n, 8) : g_wide), dim3(BLOCK), 0, stream, s->dev, np, sp,
-                                   s->d_ctr, sh, level);
+                const dim3 gr(level == 0 ? shard_grid(s, sh, n, 8) : g_wide);
+                if (level > 0) hipLaunchKernelGGL(k_resolve<true>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, level);  // camera rays are colour nodes
+                hipLaunchKernelGGL(k_resolve<false>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, level);
                 timer.end();
             }
             timer.begin(CLS_ACCUM);
@@ -907,7 +918,7 @@ int rt_query_primary(rt_scene *s, uint32_t *prim_id, double *t, double *normal3)
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, s->d_ctr, one,
                            static_cast<uint32_t>(item0), n);
         hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid_for(s, n, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, s->np, s->d_ctr, one,
-                           0u);
+                           0u, stack_entries(s));
         hipLaunchKernelGGL(k_primary_aov, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, n, d_id, d_t,
                            d_n);
         item0 += n;
@@ -952,10 +963,10 @@ int rt_trace_rays(rt_scene *s, uint32_t n, const double *origin, const double *d
         if (shadow) {
             HIP_TRY(hipMemcpy(np.t, tmax + done, m * sizeof(double), hipMemcpyHostToDevice));
             hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, s->sp,
-                               s->d_ctr, one, m);
+                               s->d_ctr, one, m, stack_entries(s));
         } else {
             hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, s->d_ctr, one,
-                               0u);
+                               0u, stack_entries(s));
         }
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(prim_id + done, np.prim, m * 4, hipMemcpyDeviceToHost));

@@ -241,6 +241,30 @@ BvhBuildResult build_bvh(const std::vector<Aabb> &boxes) {
             n.rmax[k] = q_up(rb.mx[k], k);
         }
     }
+    // ---- breadth-first order: the top of the tree becomes the first nodes of the array, which the
+    // traversal kernels keep in LDS (every ray starts there; most visits never leave it)
+    if (!(b.out.root_ref & LEAF_FLAG) && !b.out.nodes.empty()) {
+        const size_t nn = b.out.nodes.size();
+        std::vector<uint32_t> bfs;  // new index -> old index
+        bfs.reserve(nn);
+        bfs.push_back(b.out.root_ref);
+        for (size_t head = 0; head < bfs.size(); ++head) {
+            const BvhNode &n = b.out.nodes[bfs[head]];
+            if (!(n.left & LEAF_FLAG)) bfs.push_back(n.left);
+            if (!(n.right & LEAF_FLAG)) bfs.push_back(n.right);
+        }
+        std::vector<uint32_t> renum(nn, 0);
+        for (size_t i = 0; i < bfs.size(); ++i) renum[bfs[i]] = static_cast<uint32_t>(i);
+        std::vector<BvhNode> sorted(bfs.size());
+        for (size_t i = 0; i < bfs.size(); ++i) {
+            BvhNode n = b.out.nodes[bfs[i]];
+            if (!(n.left & LEAF_FLAG)) n.left = renum[n.left];
+            if (!(n.right & LEAF_FLAG)) n.right = renum[n.right];
+            sorted[i] = n;
+        }
+        b.out.nodes.swap(sorted);
+        b.out.root_ref = 0;
+    }
     return std::move(b.out);
 }
 

@@ -102,6 +102,7 @@ struct SceneDev {
     const LeafPrim *leaf_prims;
     const PlanePrim *planes;
     uint32_t root_ref;    // child-ref encoding; 0xFFFFFFFF = no bounded primitives
+    uint32_t n_top_nodes; // nodes [0, n_top_nodes) (breadth-first order: the top of the tree) are cached in LDS by the traversal kernels
     uint32_t n_planes;
     uint32_t n_bounded;
     uint32_t n_prims;

@@ -360,10 +360,20 @@ struct ObjRayCache {
     RayD r;
 };
 
+// The whole 128-byte record is requested at once (eight 16-byte loads of one cache
+// line) before anything is decided: asked for piecemeal -- meta, then the geometry
+// the type needs, then the box of a hit, then the id of an accepted hit -- a leaf
+// costs up to four dependent trips to the vector cache, and those waits, not the
+// arithmetic, are what the traversal kernels spend their time on.
 template <bool SHADOW>
 __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPrim *__restrict__ lp, const RayD &ray,
-                                               ObjRayCache &cache, double max_distance, HitRec *h, uint32_t *exact_box = nullptr) {
-    const uint32_t meta = lp->meta;
+                                               ObjRayCache &cache, double max_distance, HitRec *h, uint32_t *prim_id,
+                                               uint32_t *prim_type = nullptr, uint32_t *exact_box = nullptr) {
+    const double2 *q = reinterpret_cast<const double2 *>(lp);
+    const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+    const uint4 tail = reinterpret_cast<const uint4 *>(lp)[7];  // geom[8] | prim_id | meta
+    const uint32_t meta = tail.w;
+    *prim_id = tail.z;
     const uint32_t xf = meta >> 4;
     if (xf != cache.xf) {  // Ray::transform (ray_intersection.rs:33-43), shared by a mesh's faces
         const double *inv = sc.inv_world + 12ull * xf;
@@ -372,11 +382,11 @@ __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPri
         cache.xf = xf;
     }
     const uint32_t type = meta & 3u, side = (meta >> 2) & 3u;
+    if (prim_type) *prim_type = type;
+    const double geom[9] = {q3.x, q3.y, q4.x, q4.y, q5.x, q5.y, q6.x, q6.y,
+                            __hiloint2double(static_cast<int>(tail.y), static_cast<int>(tail.x))};
     double t_probe;
-    if (!hit_bounded<SHADOW>(lp->geom, type, side, cache.r, max_distance, h, &t_probe)) return false;
-    // centre / half-extent: three 16-byte loads (the kernels are bound by vector-memory instruction issue)
-    const double2 *q = reinterpret_cast<const double2 *>(lp);
-    const double2 q0 = q[0], q1 = q[1], q2 = q[2];
+    if (!hit_bounded<SHADOW>(geom, type, side, cache.r, max_distance, h, &t_probe)) return false;
     const double center[3] = {q0.x, q0.y, q1.x}, half[3] = {q1.y, q2.x, q2.y};
     if (prim_box_surely_passes(center, half, ray, t_probe, SHADOW, max_distance)) return true;
     if (exact_box) *exact_box = 1u;
@@ -385,20 +395,44 @@ __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPri
 
 __device__ __forceinline__ double cull_limit(double t) { return t + 1e-9 * (1.0 + fabs(t)); }
 
+// The block's copy of the top of the tree (nodes [0, n_top_nodes), breadth-first
+// order) sits in LDS behind the stacks: every ray starts there and most node
+// visits never leave it, which takes them off the vector-memory path that bounds
+// these kernels (two divergent 16-byte loads per visit otherwise).
+__device__ __forceinline__ const uint4 *stage_top_nodes(const SceneDev &sc, uint32_t *stack_lds, uint32_t stack_entries) {
+    uint4 *top = reinterpret_cast<uint4 *>(stack_lds + stack_entries * BLOCK);
+    const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes);
+    for (uint32_t i = threadIdx.x; i < sc.n_top_nodes * 2u; i += BLOCK) top[i] = src[i];
+    __syncthreads();
+    return top;
+}
+
 // Descend from `cur` through interior nodes until a leaf ref or the sentinel.
 template <bool COUNT>
-__device__ __forceinline__ uint32_t descend(const SceneDev &sc, const CullRay &cr, float limit, uint32_t cur, uint32_t *stack,
-                                            uint32_t &sp, unsigned long long &n_nodes) {
+__device__ __forceinline__ uint32_t descend(const SceneDev &sc, const uint4 *top_nodes, const CullRay &cr, float limit, uint32_t cur,
+                                            uint32_t *stack, uint32_t &sp, unsigned long long &n_nodes) {
     while (!(cur & LEAF_FLAG) && cur != STACK_SENTINEL) {
-        const BvhNode *nd = sc.nodes + cur;
+        uint4 w0, w1;  // the 32-byte node: lmin lmax rmin | rmax left right
+        if (cur < sc.n_top_nodes) {
+            w0 = top_nodes[2u * cur];
+            w1 = top_nodes[2u * cur + 1u];
+        } else {
+            const uint4 *g = reinterpret_cast<const uint4 *>(sc.nodes + cur);
+            w0 = g[0];
+            w1 = g[1];
+        }
         if (COUNT) {  // low 40 bits: lane-level visits; high bits: wave-level visits (counted by the first active lane)
             n_nodes++;
             if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(__ballot(true)) - 1)) n_nodes += 1ull << 40;
         }
+        const uint16_t lmin[3] = {static_cast<uint16_t>(w0.x), static_cast<uint16_t>(w0.x >> 16), static_cast<uint16_t>(w0.y)};
+        const uint16_t lmax[3] = {static_cast<uint16_t>(w0.y >> 16), static_cast<uint16_t>(w0.z), static_cast<uint16_t>(w0.z >> 16)};
+        const uint16_t rmin[3] = {static_cast<uint16_t>(w0.w), static_cast<uint16_t>(w0.w >> 16), static_cast<uint16_t>(w1.x)};
+        const uint16_t rmax[3] = {static_cast<uint16_t>(w1.x >> 16), static_cast<uint16_t>(w1.y), static_cast<uint16_t>(w1.y >> 16)};
         float tl, tr;
-        const bool hl = box_cull_test(nd->lmin, nd->lmax, cr, limit, &tl);
-        const bool hr = box_cull_test(nd->rmin, nd->rmax, cr, limit, &tr);
-        const uint32_t lref = nd->left, rref = nd->right;
+        const bool hl = box_cull_test(lmin, lmax, cr, limit, &tl);
+        const bool hr = box_cull_test(rmin, rmax, cr, limit, &tr);
+        const uint32_t lref = w1.z, rref = w1.w;
         if (hl && hr) {
             const bool left_first = !(tr < tl);
             stack[(sp++) * BLOCK] = left_first ? rref : lref;
@@ -425,11 +459,12 @@ __device__ __forceinline__ uint32_t descend(const SceneDev &sc, const CullRay &c
 // is 80 % of all nodes.
 template <bool COUNT, bool FINALIZE>
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev sc, NodePool np, Counters *ctrs, Shards shards,
-                                                        uint32_t level) {
-    extern __shared__ uint32_t stack_lds[];
+                                                        uint32_t level, uint32_t stack_entries) {
+    extern __shared__ __align__(16) uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;
     __shared__ LevelMap map;
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
+    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
     unsigned long long n_nodes = 0, n_prims = 0;
     for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
@@ -473,7 +508,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
             uint32_t sp = 1;
             uint32_t cur = sc.root_ref;
             while (true) {
-                cur = descend<COUNT>(sc, cr, cull_limit_f32(cull_limit(best_t)), cur, stack, sp, n_nodes);
+                cur = descend<COUNT>(sc, top_nodes, cr, cull_limit_f32(cull_limit(best_t)), cur, stack, sp, n_nodes);
                 if (cur == STACK_SENTINEL) break;
                 const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
                 if (COUNT && (threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(__ballot(true)) - 1)) n_prims += 1ull << 40;  // wave-level leaf round
@@ -481,10 +516,9 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
                     const LeafPrim *lp = sc.leaf_prims + first + k;
                     HitRec h;
                     if (COUNT) n_prims++;
-                    uint32_t exact_box = 0;
-                    const bool leaf_hit = test_leaf_prim<false>(sc, lp, ray, cache, 0.0, &h, COUNT ? &exact_box : nullptr);
+                    uint32_t exact_box = 0, pid, ty = 0;
+                    const bool leaf_hit = test_leaf_prim<false>(sc, lp, ray, cache, 0.0, &h, &pid, COUNT ? &ty : nullptr, COUNT ? &exact_box : nullptr);
                     if (COUNT) {  // census of the wave's leaf round: which primitive types are present, how many lanes, exact box tests
-                        const uint32_t ty = lp->meta & 3u;
                         const unsigned long long m_all = __ballot(true), m_t = __ballot(ty == RT_PRIM_TRIANGLE), m_s = __ballot(ty == RT_PRIM_SPHERE),
                                                  m_c = __ballot(ty == RT_PRIM_CUBE), m_x = __ballot(exact_box != 0), m_h = __ballot(leaf_hit);
                         if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(m_all) - 1)) {
@@ -495,7 +529,6 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
                         }
                     }
                     if (leaf_hit) {
-                        const uint32_t pid = lp->prim_id;
                         bool better = best_id == RT_NO_HIT || h.t < best_t || (h.t == best_t && best_bounded && pid < best_id);
                         if (better) {
                             best_t = h.t;
@@ -562,11 +595,12 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
 // PROBE: rays come from the node pool (rt_trace_rays) instead of the shadow pool.
 template <bool COUNT, bool PROBE>
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc, NodePool np, ShadowPool sp_pool, Counters *ctrs,
-                                                       Shards shards, uint32_t probe_count) {
-    extern __shared__ uint32_t stack_lds[];
+                                                       Shards shards, uint32_t probe_count, uint32_t stack_entries) {
+    extern __shared__ __align__(16) uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;
     __shared__ LevelMap map;
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
+    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const uint32_t n_groups = PROBE ? (probe_count + 63u) / 64u : level_map_build(map, ctrs, shards, 0u, true);
     unsigned long long n_nodes = 0, n_prims = 0;
     for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
@@ -614,13 +648,14 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
             uint32_t sp = 1;
             uint32_t cur = sc.root_ref;
             while (true) {
-                cur = descend<COUNT>(sc, cr, limit, cur, stack, sp, n_nodes);
+                cur = descend<COUNT>(sc, top_nodes, cr, limit, cur, stack, sp, n_nodes);
                 if (cur == STACK_SENTINEL) break;
                 const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
                 for (uint32_t k = 0; k < n && !occluded; ++k) {
                     HitRec h;
                     if (COUNT) n_prims++;
-                    if (test_leaf_prim<true>(sc, sc.leaf_prims + first + k, ray, cache, tmax, &h)) occluded = true;
+                    uint32_t pid;
+                    if (test_leaf_prim<true>(sc, sc.leaf_prims + first + k, ray, cache, tmax, &h, &pid)) occluded = true;
                 }
                 if (occluded) break;
                 cur = stack[(--sp) * BLOCK];
@@ -661,13 +696,15 @@ struct WaveQueue {
 __device__ __forceinline__ void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 // Scans until 64 live nodes are queued or the wave's share of the level's groups
-// is exhausted; returns how many to process now (0 = finished).
+// is exhausted; returns how many to process now (0 = finished).  A node is live
+// when (meta & live_mask) == live_value.
 __device__ __forceinline__ uint32_t queue_fill(WaveQueue &wq, const uint32_t *__restrict__ meta, const LevelMap &map,
-                                              const Shards &shards, uint32_t n_groups, uint32_t stride, uint32_t lane) {
+                                              const Shards &shards, uint32_t n_groups, uint32_t stride, uint32_t lane,
+                                              uint32_t live_mask = META_INACTIVE | META_DONE, uint32_t live_value = 0u) {
     while (wq.n < 64u && wq.base < n_groups) {
         uint32_t n_valid;
         const uint32_t idx = level_map_group(map, shards, wq.base, &n_valid) + lane;
-        const bool live = lane < n_valid && !(meta[idx] & (META_INACTIVE | META_DONE));
+        const bool live = lane < n_valid && (meta[idx] & live_mask) == live_value;
         const unsigned long long mask = __ballot(live);
         if (live) wq.q[wq.n + __popcll(mask & ((1ull << lane) - 1ull))] = idx;
         wq.n += static_cast<uint32_t>(__popcll(mask));
@@ -921,7 +958,11 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
 // ------------------------------------------------------------------ resolve
 // Bottom-up shading of every node of `level`; children of level+1 are resolved.
 // Result: (t,bu,bv) <- RGB, prim <- flag (illumination nodes: occluded).
-__global__ __launch_bounds__(BLOCK, RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
+// Two instantiations per level: illumination nodes (get_emissive_*: a few loads, a
+// few multiplies) and colour nodes (the full shading; register heavy), so that the
+// illumination nodes do not run at the colour path's two waves per SIMD.
+template <bool ILLUM>
+__global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
                                                   uint32_t level) {
     __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
     __shared__ LevelMap map;
@@ -933,7 +974,9 @@ __global__ __launch_bounds__(BLOCK, RESOLVE_WAVES) void k_resolve(SceneDev sc, N
     wq.n = 0;
     wq.base = blockIdx.x * (BLOCK / 64) + (tid >> 6);
     const uint32_t wave_stride = gridDim.x * (BLOCK / 64);
-    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, map, shards, n_groups, wave_stride, lane)) != 0; queue_pop(wq, n_proc, lane)) {
+    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, map, shards, n_groups, wave_stride, lane, META_INACTIVE | META_DONE | META_ILLUM,
+                                               ILLUM ? META_ILLUM : 0u)) != 0;
+         queue_pop(wq, n_proc, lane)) {
         if (lane >= n_proc) continue;
         const uint32_t idx = wq.q[lane];
         const uint32_t meta = np.meta[idx];
@@ -941,7 +984,7 @@ __global__ __launch_bounds__(BLOCK, RESOLVE_WAVES) void k_resolve(SceneDev sc, N
         d3 result = mk3(0.0, 0.0, 0.0);
         uint32_t flag = 0;
         if (prim != RT_NO_HIT) {
-            const bool illum = (meta & META_ILLUM) != 0;
+            constexpr bool illum = ILLUM;
             const d3 o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
             const d3 d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
             const double t = np.t[idx], bu = np.bu[idx], bv = np.bv[idx];
