@@ -111,46 +111,59 @@ __device__ __forceinline__ void rng_pair(uint64_t seed, uint32_t pixel, uint32_t
 }
 
 // ------------------------------------------------------------------ sampling (src/utils/sampling.rs)
-__device__ __forceinline__ d3 sample_cosine_hemisphere(d3 w, double u1, double u2) {
-    constexpr double HALF_PI = 1.57079632679489661923, QUARTER_PI = 0.78539816339744830962;
-    double rx = 2.0 * u1 - 1.0, ry = 2.0 * u2 - 1.0;
-    double px = 0.0, py = 0.0;
-    if (!(rx == 0.0 && ry == 0.0)) {
-        double r, theta;
-        if (fabs(rx) > fabs(ry)) {
+// cosine_sample_hemisphere (sampling.rs:6-37, with concentric_sample_disk) and
+// uniform_sample_cone (:39-70) as ONE routine: a wave of child rays mixes cone
+// samples (reflections of physical materials) and hemisphere samples (GI rays),
+// and as two routines it ran both, each with part of its lanes.  Here the pieces
+// both need -- sincos of the first angle, the final normalisation -- are reached by
+// all lanes together; every expression is the one the reference evaluates.
+constexpr uint32_t SAMPLE_NONE = 0u, SAMPLE_CONE = 1u, SAMPLE_HEMISPHERE = 2u;
+__device__ __forceinline__ d3 sample_direction(uint32_t kind, d3 w, double max_angle, double u1, double u2) {
+    constexpr double HALF_PI = 1.57079632679489661923, QUARTER_PI = 0.78539816339744830962, TWO_PI = 6.28318530717958647692;
+    if (kind == SAMPLE_CONE && max_angle < F64_EPS) kind = SAMPLE_NONE;  // :43-45
+    double theta = 0.0, r = 0.0;
+    bool centre = false;  // hemisphere: the disk sample is the origin (:10-12)
+    if (kind == SAMPLE_CONE) {
+        theta = acos(u1);
+        theta = theta * max_angle / HALF_PI;
+    } else if (kind == SAMPLE_HEMISPHERE) {
+        const double rx = 2.0 * u1 - 1.0, ry = 2.0 * u2 - 1.0;
+        if (rx == 0.0 && ry == 0.0) {
+            centre = true;
+        } else if (fabs(rx) > fabs(ry)) {
             r = rx;
             theta = HALF_PI * (ry / rx);
         } else {
             r = ry;
             theta = HALF_PI - QUARTER_PI * (rx / ry);
         }
-        double st, ct;
-        sincos(theta, &st, &ct);  // one argument reduction for both
-        px = r * ct;
-        py = r * st;
     }
-    double pz = sqrt(1.0 - px * px - py * py);
-    d3 u = fabs(w.x) > F64_EPS ? cross3(w, mk3(0.0, 1.0, 0.0)) : cross3(w, mk3(1.0, 0.0, 0.0));
-    d3 v = cross3(w, u);
-    return unit3(u * px + v * py + w * pz);
-}
-
-__device__ __forceinline__ d3 sample_cone(d3 w, double max_angle, double u1, double u2) {
-    constexpr double HALF_PI = 1.57079632679489661923, TWO_PI = 6.28318530717958647692;
-    if (max_angle < F64_EPS) return w;
-    double theta = acos(u1);
-    theta = theta * max_angle / HALF_PI;
-    double z, radius;
-    sincos(theta, &radius, &z);
-    double phi = u2 * TWO_PI;
-    double sp, cp;
-    sincos(phi, &sp, &cp);
-    d3 u = cross3(w, mk3(0.0, 0.0, 1.0));
-    double mag = length3(u);
-    if (mag < F64_EPS) return unit3(mk3(radius * cp, radius * sp, rsign(w.z) * z));
-    u = unit3(u);
-    d3 v = unit3(cross3(w, u));
-    return unit3(u * radius * cp + v * radius * sp + w * z);
+    if (kind == SAMPLE_NONE) return w;
+    double st, ct;
+    sincos(theta, &st, &ct);  // one argument reduction for both
+    d3 raw;
+    if (kind == SAMPLE_CONE) {
+        const double z = ct, radius = st;
+        const double phi = u2 * TWO_PI;
+        double sp, cp;
+        sincos(phi, &sp, &cp);
+        d3 u = cross3(w, mk3(0.0, 0.0, 1.0));
+        const double mag = length3(u);
+        if (mag < F64_EPS) {
+            raw = mk3(radius * cp, radius * sp, rsign(w.z) * z);
+        } else {
+            u = unit3(u);
+            const d3 v = unit3(cross3(w, u));
+            raw = u * radius * cp + v * radius * sp + w * z;
+        }
+    } else {
+        const double px = centre ? 0.0 : r * ct, py = centre ? 0.0 : r * st;
+        const double pz = sqrt(1.0 - px * px - py * py);
+        const d3 u = fabs(w.x) > F64_EPS ? cross3(w, mk3(0.0, 1.0, 0.0)) : cross3(w, mk3(1.0, 0.0, 0.0));
+        const d3 v = cross3(w, u);
+        raw = u * px + v * py + w * pz;
+    }
+    return unit3(raw);
 }
 
 // src/utils/rays.rs

@@ -913,32 +913,31 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
             const uint32_t slot = j - (L.incl_nodes[p] - (pR + pT + pG));
             const uint64_t path = L.path[p];
             const d3 P = mk3(L.Px[p], L.Py[p], L.Pz[p]);
-            d3 dir;
+            // which sampler, about which axis; the draw and the sampler itself are reached by all lanes together
+            d3 axis;
             uint64_t cpath;
-            uint32_t cmeta;
+            uint32_t cmeta, kind;
+            double max_angle = 0.0;
             if (slot < pR) {
-                const d3 rdir = mk3(L.rx[p], L.ry[p], L.rz[p]);
+                axis = mk3(L.rx[p], L.ry[p], L.rz[p]);
                 cpath = path_child(path, slot);
                 cmeta = L.meta_same[p];
-                if (cnt & 0x80000000u) {  // phong mirror: no sampling
-                    dir = rdir;
-                } else {
-                    double u1, u2;
-                    rng_pair(wl.seed, L.pixel[p], L.sample[p], cpath, &u1, &u2);
-                    dir = sample_cone(rdir, L.max_angle[p], u1, u2);
-                }
+                kind = (cnt & 0x80000000u) ? SAMPLE_NONE : SAMPLE_CONE;  // phong mirror: the direction itself
+                max_angle = L.max_angle[p];
             } else if (slot < pR + pT) {
-                dir = mk3(L.tx[p], L.ty[p], L.tz[p]);
+                axis = mk3(L.tx[p], L.ty[p], L.tz[p]);
                 cpath = path_child(path, SLOT_REFRACTION);
                 cmeta = L.meta_refr[p];
+                kind = SAMPLE_NONE;
             } else {
-                const uint32_t g = slot - pR - pT;
-                cpath = path_child(path, SLOT_GI + g);
-                double u1, u2;
-                rng_pair(wl.seed, L.pixel[p], L.sample[p], cpath, &u1, &u2);
-                dir = sample_cosine_hemisphere(mk3(L.nx[p], L.ny[p], L.nz[p]), u1, u2);
+                axis = mk3(L.nx[p], L.ny[p], L.nz[p]);
+                cpath = path_child(path, SLOT_GI + (slot - pR - pT));
                 cmeta = child_depth | META_ILLUM;
+                kind = SAMPLE_HEMISPHERE;
             }
+            double u1 = 0.0, u2 = 0.0;
+            if (kind != SAMPLE_NONE) rng_pair(wl.seed, L.pixel[p], L.sample[p], cpath, &u1, &u2);
+            const d3 dir = sample_direction(kind, axis, max_angle, u1, u2);
             const d3 org = P + dir * BIAS;
             const uint32_t at = node_base + j;
             np.ox[at] = org.x;
