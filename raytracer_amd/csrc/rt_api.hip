@@ -213,12 +213,9 @@ int ensure_pools(rt_scene *s) {
         return r;
     };
     NodePool &np = s->np;
-    np.ox = reinterpret_cast<double *>(take(cap * 8));
-    np.oy = reinterpret_cast<double *>(take(cap * 8));
-    np.oz = reinterpret_cast<double *>(take(cap * 8));
-    np.dx = reinterpret_cast<double *>(take(cap * 8));
-    np.dy = reinterpret_cast<double *>(take(cap * 8));
-    np.dz = reinterpret_cast<double *>(take(cap * 8));
+    np.r0 = reinterpret_cast<Vec2d *>(take(cap * 16));
+    np.r1 = reinterpret_cast<Vec2d *>(take(cap * 16));
+    np.r2 = reinterpret_cast<Vec2d *>(take(cap * 16));
     np.path = reinterpret_cast<uint64_t *>(take(cap * 8));
     np.t = reinterpret_cast<double *>(take(cap * 8));
     np.bu = reinterpret_cast<double *>(take(cap * 8));
@@ -226,16 +223,11 @@ int ensure_pools(rt_scene *s) {
     np.root = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.meta = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.prim = reinterpret_cast<uint32_t *>(take(cap * 4));
-    np.first_child = reinterpret_cast<uint32_t *>(take(cap * 4));
-    np.first_shadow = reinterpret_cast<uint32_t *>(take(cap * 4));
-    np.counts = reinterpret_cast<uint32_t *>(take(cap * 4));
-    np.light_mask = reinterpret_cast<uint32_t *>(take(cap * 4));
+    np.xinfo = reinterpret_cast<ExpandInfo *>(take(cap * 16));
     np.capacity = static_cast<uint32_t>(cap);
     ShadowPool &sp = s->sp;
-    sp.dx = reinterpret_cast<double *>(take(scap * 8));
-    sp.dy = reinterpret_cast<double *>(take(scap * 8));
-    sp.dz = reinterpret_cast<double *>(take(scap * 8));
-    sp.tmax = reinterpret_cast<double *>(take(scap * 8));
+    sp.s0 = reinterpret_cast<Vec2d *>(take(scap * 16));
+    sp.s1 = reinterpret_cast<Vec2d *>(take(scap * 16));
     sp.light = reinterpret_cast<uint8_t *>(take(scap));
     sp.occluded = reinterpret_cast<uint8_t *>(take(scap));
     sp.capacity = static_cast<uint32_t>(scap);
@@ -945,17 +937,18 @@ int rt_trace_rays(rt_scene *s, uint32_t n, const double *origin, const double *d
     uint32_t done = 0;
     while (done < n) {
         const uint32_t m = std::min<uint32_t>(n - done, np.capacity);
-        col.resize(m);
-        auto put = [&](double *dst, const double *src, int comp) -> hipError_t {
-            for (uint32_t i = 0; i < m; ++i) col[i] = src[3ull * (done + i) + comp];
-            return hipMemcpy(dst, col.data(), m * sizeof(double), hipMemcpyHostToDevice);
+        col.resize(2ull * m);
+        // the ray as the node pool holds it: (o.x, o.y) (o.z, d.x) (d.y, d.z)
+        auto put = [&](Vec2d *dst, const double *a, int ca, const double *b, int cb) -> hipError_t {
+            for (uint32_t i = 0; i < m; ++i) {
+                col[2ull * i] = a[3ull * (done + i) + ca];
+                col[2ull * i + 1] = b[3ull * (done + i) + cb];
+            }
+            return hipMemcpy(dst, col.data(), 2ull * m * sizeof(double), hipMemcpyHostToDevice);
         };
-        HIP_TRY(put(np.ox, origin, 0));
-        HIP_TRY(put(np.oy, origin, 1));
-        HIP_TRY(put(np.oz, origin, 2));
-        HIP_TRY(put(np.dx, dir, 0));
-        HIP_TRY(put(np.dy, dir, 1));
-        HIP_TRY(put(np.dz, dir, 2));
+        HIP_TRY(put(np.r0, origin, 0, origin, 1));
+        HIP_TRY(put(np.r1, origin, 2, dir, 0));
+        HIP_TRY(put(np.r2, dir, 1, dir, 2));
         meta.assign(m, 1u);  // depth 1 secondary
         HIP_TRY(hipMemcpy(np.meta, meta.data(), m * 4, hipMemcpyHostToDevice));
         const Shards one = single_shard(s);

@@ -139,28 +139,33 @@ constexpr uint32_t META_INACTIVE = 32u;
 constexpr uint32_t META_DONE = 128u;  // bit 7: result already final (set by k_trace_closest), nothing to expand or resolve
 constexpr uint32_t META_MAT_SHIFT = 8u;
 
-// SoA node pool.  After resolve, (t,bu,bv) hold the node's RGB result and
-// `prim` its flag word (illumination nodes: 1 = occluded).
+// Node pool: structure of arrays of 16-byte elements where a record's fields travel
+// together (one 16-byte access per lane is the widest, and a wave's 64 of them are
+// 1 KB contiguous), plain words where a field is scanned or rewritten on its own.
+// After resolve, (t,bu,bv) hold the node's RGB result and `prim` its flag word
+// (bit 0: occluded, illumination nodes; bit 1: RGB is not all zero).
+struct alignas(16) Vec2d {
+    double x, y;
+};
+struct alignas(16) ExpandInfo {
+    uint32_t first_child, first_shadow;
+    uint32_t counts;      // nR | nT << 16 | nG << 17
+    uint32_t light_mask;  // point lights that cast a shadow ray
+};
 struct NodePool {
-    double *ox, *oy, *oz;
-    double *dx, *dy, *dz;
+    Vec2d *r0, *r1, *r2;  // ray: (o.x, o.y) (o.z, d.x) (d.y, d.z)
     uint64_t *path;
     uint32_t *root;  // camera-ray index within the call's work list
     uint32_t *meta;
     // hit / result
     uint32_t *prim;
     double *t, *bu, *bv;
-    // expansion info
-    uint32_t *first_child;
-    uint32_t *first_shadow;
-    uint32_t *counts;      // nR | nT << 16 | nG << 17
-    uint32_t *light_mask;  // point lights that cast a shadow ray
+    ExpandInfo *xinfo;  // written by k_expand for the nodes it expands, read by k_resolve
     uint32_t capacity;
 };
 
 struct ShadowPool {
-    double *dx, *dy, *dz;
-    double *tmax;
+    Vec2d *s0, *s1;     // (d.x, d.y) (d.z, tmax); the origin is the light's position
     uint8_t *light;     // index among point lights
     uint8_t *occluded;  // result
     uint32_t capacity;

@@ -31,6 +31,16 @@ constexpr double HALF_PI_D = 1.57079632679489661923;
 constexpr double INV_PI_D = 0.318309886183790671538;
 
 // ------------------------------------------------------------------ helpers
+__device__ __forceinline__ void load_ray(const NodePool &np, uint32_t i, d3 *o, d3 *d) {
+    const Vec2d a = np.r0[i], b = np.r1[i], c = np.r2[i];
+    *o = mk3(a.x, a.y, b.x);
+    *d = mk3(b.y, c.x, c.y);
+}
+__device__ __forceinline__ void store_ray(const NodePool &np, uint32_t i, d3 o, d3 d) {
+    np.r0[i] = Vec2d{o.x, o.y};
+    np.r1[i] = Vec2d{o.z, d.x};
+    np.r2[i] = Vec2d{d.y, d.z};
+}
 __device__ __forceinline__ void item_to_pixel(const WorkList &wl, uint32_t item, uint32_t *px, uint32_t *py,
                                               uint32_t *sample) {
     uint32_t s_local = item % wl.ns;
@@ -320,12 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev sc, WorkList wl, Node
         const double *m = sc.cam_to_world;
         d3 wd = mk3(m[0] * dir.x + m[1] * dir.y + m[2] * dir.z, m[3] * dir.x + m[4] * dir.y + m[5] * dir.z,
                     m[6] * dir.x + m[7] * dir.y + m[8] * dir.z);
-        np.ox[i] = sc.cam_pos[0];
-        np.oy[i] = sc.cam_pos[1];
-        np.oz[i] = sc.cam_pos[2];
-        np.dx[i] = wd.x;
-        np.dy[i] = wd.y;
-        np.dz[i] = wd.z;
+        store_ray(np, i, mk3(sc.cam_pos[0], sc.cam_pos[1], sc.cam_pos[2]), wd);
     }
     if (n_active) atomicAdd(&ctr->active_camera, n_active);
 }
@@ -477,8 +482,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
             continue;
         }
         RayD ray;
-        ray.o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
-        ray.d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
+        load_ray(np, idx, &ray.o, &ray.d);
         double best_t = __builtin_inf();
         uint32_t best_id = RT_NO_HIT;
         double best_bu = 0.0, best_bv = 0.0;
@@ -616,14 +620,14 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
         RayD ray;
         double tmax;
         if (PROBE) {
-            ray.o = mk3(np.ox[i], np.oy[i], np.oz[i]);
-            ray.d = mk3(np.dx[i], np.dy[i], np.dz[i]);
+            load_ray(np, i, &ray.o, &ray.d);
             tmax = np.t[i];
         } else {
             const DLight &l = sc.lights[sp_pool.light[i]];
             ray.o = mk3(l.position[0], l.position[1], l.position[2]);
-            ray.d = mk3(sp_pool.dx[i], sp_pool.dy[i], sp_pool.dz[i]);
-            tmax = sp_pool.tmax[i];
+            const Vec2d a = sp_pool.s0[i], b = sp_pool.s1[i];
+            ray.d = mk3(a.x, a.y, b.x);
+            tmax = b.y;
         }
         bool occluded = false;
         for (uint32_t p = 0; p < sc.n_planes && !occluded; ++p) {
@@ -775,8 +779,8 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
         }
         if (prim != RT_NO_HIT) {
             const bool illum = (meta & META_ILLUM) != 0;
-            const d3 o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
-            const d3 d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
+            d3 o, d;
+            load_ray(np, idx, &o, &d);
             const ShadePrim &sh = sc.shade_prims[prim];
             const rt_material &m = sc.materials[sh.material];
             const Surface s = compute_surface(sc, sh, m.side, o, d, np.t[idx], np.bu[idx], np.bv[idx]);
@@ -872,10 +876,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
         L.incl_nodes[tid] = first_child - node_base + total;
         L.incl_shadows[tid] = first_shadow - shadow_base + nS;
         if (valid) {
-            np.first_child[idx] = first_child;
-            np.first_shadow[idx] = first_shadow;
-            np.counts[idx] = nR | (nT << 16) | (nG << 17);
-            np.light_mask[idx] = mask;
+            np.xinfo[idx] = ExpandInfo{first_child, first_shadow, nR | (nT << 16) | (nG << 17), mask};
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // phase A's LDS stores -> phase B's reads (same wave)
 
@@ -899,10 +900,8 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
             const double dist = length3(ld);
             ld = unit3(ld);
             const uint32_t k = shadow_base + j;
-            sp.dx[k] = -ld.x;
-            sp.dy[k] = -ld.y;
-            sp.dz[k] = -ld.z;
-            sp.tmax[k] = dist - BIAS;  // shadow_cast(.., max_distance - BIAS), :94-96
+            sp.s0[k] = Vec2d{-ld.x, -ld.y};
+            sp.s1[k] = Vec2d{-ld.z, dist - BIAS};  // shadow_cast(.., max_distance - BIAS), :94-96
             sp.light[k] = static_cast<uint8_t>(li);
         }
         // ---- phase B: child rays
@@ -940,12 +939,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
             const d3 dir = sample_direction(kind, axis, max_angle, u1, u2);
             const d3 org = P + dir * BIAS;
             const uint32_t at = node_base + j;
-            np.ox[at] = org.x;
-            np.oy[at] = org.y;
-            np.oz[at] = org.z;
-            np.dx[at] = dir.x;
-            np.dy[at] = dir.y;
-            np.dz[at] = dir.z;
+            store_ray(np, at, org, dir);
             np.path[at] = cpath;
             np.root[at] = L.root[p];
             np.meta[at] = cmeta;
@@ -984,17 +978,18 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
         uint32_t flag = 0;
         if (prim != RT_NO_HIT) {
             constexpr bool illum = ILLUM;
-            const d3 o = mk3(np.ox[idx], np.oy[idx], np.oz[idx]);
-            const d3 d = mk3(np.dx[idx], np.dy[idx], np.dz[idx]);
+            d3 o, d;
+            load_ray(np, idx, &o, &d);
             const double t = np.t[idx], bu = np.bu[idx], bv = np.bv[idx];
             const ShadePrim &sh = sc.shade_prims[prim];
             const rt_material &m = sc.materials[sh.material];
             const Surface s = compute_surface(sc, sh, m.side, o, d, t, bu, bv);
             const d3 mc = material_color(sc, sh, m, s, bu, bv);
             const d3 emissive = mk3(m.emissive[0], m.emissive[1], m.emissive[2]);
-            const uint32_t counts = np.counts[idx];
+            const ExpandInfo xi = np.xinfo[idx];
+            const uint32_t counts = xi.counts;
             const uint32_t nT = (counts >> 16) & 1u;
-            uint32_t child = np.first_child[idx];
+            uint32_t child = xi.first_child;
             // a resolved child: word bit 1 says whether its RGB is non-zero (4 of 5 are black: one load instead of four)
             auto child_rgb = [&](uint32_t at) { return (np.prim[at] & 2u) ? mk3(np.t[at], np.bu[at], np.bv[at]) : mk3(0.0, 0.0, 0.0); };
 
@@ -1081,8 +1076,8 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
                 // ---- direct lighting
                 d3 ambient = mk3(0.0, 0.0, 0.0), irradiance = mk3(0.0, 0.0, 0.0);
                 if (m.kind == RT_MAT_PHYSICAL || m.reflectivity < 1.0) {
-                    const uint32_t mask = np.light_mask[idx];
-                    uint32_t bit = 0, k = np.first_shadow[idx];
+                    const uint32_t mask = xi.light_mask;
+                    uint32_t bit = 0, k = xi.first_shadow;
                     for (uint32_t li = 0; li < sc.n_lights; ++li) {
                         const DLight &l = sc.lights[li];
                         if (l.kind == RT_LIGHT_AMBIENT) {
@@ -1219,7 +1214,8 @@ __global__ __launch_bounds__(BLOCK) void k_primary_aov(SceneDev sc, WorkList wl,
         }
         const ShadePrim &sh = sc.shade_prims[prim];
         const rt_material &m = sc.materials[sh.material];
-        const d3 o = mk3(np.ox[i], np.oy[i], np.oz[i]), d = mk3(np.dx[i], np.dy[i], np.dz[i]);
+        d3 o, d;
+        load_ray(np, i, &o, &d);
         const Surface s = compute_surface(sc, sh, m.side, o, d, np.t[i], np.bu[i], np.bv[i]);
         out_t[at] = np.t[i];
         out_n[3 * at] = s.n.x;
