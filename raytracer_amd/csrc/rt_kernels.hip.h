@@ -988,28 +988,48 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
             const d3 emissive = mk3(m.emissive[0], m.emissive[1], m.emissive[2]);
             const ExpandInfo xi = np.xinfo[idx];
             const uint32_t counts = xi.counts;
-            const uint32_t nT = (counts >> 16) & 1u;
-            uint32_t child = xi.first_child;
-            // a resolved child: word bit 1 says whether its RGB is non-zero (4 of 5 are black: one load instead of four)
-            auto child_rgb = [&](uint32_t at) { return (np.prim[at] & 2u) ? mk3(np.t[at], np.bu[at], np.bv[at]) : mk3(0.0, 0.0, 0.0); };
+            // ---- children, one pass in slot order [reflection x nR][refraction x nT][GI x nG] (counts are zero when the
+            // next level is cut off).  Their result words are read four at a time (aligned 16-byte loads over the
+            // block of children); bit 1 of a word says whether its RGB is non-zero (4 of 5 are black: nothing more to
+            // load), bit 0 "occluded".  Each class is summed in slot order, as the reference's loops do.
+            const uint32_t nR = counts & 0xFFFFu, nT = (counts >> 16) & 1u, nG = (counts >> 17) & 0x3FFFu;
+            const bool clamp_each = !ILLUM && m.kind == RT_MAT_PHYSICAL;  // :380 adds clamped colours; :299 and :196 raw ones
+            d3 refl_sum = mk3(0.0, 0.0, 0.0), refr_rgb = mk3(0.0, 0.0, 0.0), gi_sum = mk3(0.0, 0.0, 0.0);
+            uint32_t unoccluded = 0;
+            {
+                const uint32_t first = xi.first_child, end = first + nR + nT + nG;
+                for (uint32_t a4 = first & ~3u; a4 < end; a4 += 4u) {
+                    const uint4 w4 = *reinterpret_cast<const uint4 *>(np.prim + a4);
+                    const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const uint32_t at = a4 + j;
+                        if (at < first || at >= end) continue;
+                        const uint32_t slot = at - first;
+                        d3 rgb = mk3(0.0, 0.0, 0.0);
+                        if (w[j] & 2u) rgb = mk3(np.t[at], np.bu[at], np.bv[at]);
+                        if (slot < nR) {
+                            refl_sum = refl_sum + (clamp_each ? sat01(rgb) : rgb);
+                        } else if (slot < nR + nT) {
+                            refr_rgb = rgb;
+                        } else {
+                            if (w[j] & 2u) gi_sum = gi_sum + rgb;
+                            if (!(w[j] & 1u)) unoccluded++;
+                        }
+                    }
+                }
+            }
 
             if (illum) {
                 // get_emissive_phong :135-167 / get_emissive_physical :263-337
                 if (m.kind == RT_MAT_PHONG) {
                     result = emissive;
-                    if (m.reflectivity > 0.0) {
-                        d3 incoming = next_real ? child_rgb(child) : mk3(0.0, 0.0, 0.0);
-                        result = result + hadamard(incoming, mc) * m.reflectivity;
-                    }
+                    if (m.reflectivity > 0.0) result = result + hadamard(refl_sum, mc) * m.reflectivity;
                 } else {
                     result = emissive;
                     if (sc.opts.max_reflected_rays > 0) {
                         const uint32_t n = refl_rays(sc, level);
-                        d3 acc = mk3(0.0, 0.0, 0.0);
-                        for (uint32_t r = 0; r < n; ++r)
-                            acc = acc + (next_real ? child_rgb(child + r) : mk3(0.0, 0.0, 0.0));
-                        if (next_real) child += n;
-                        acc = acc * (HALF_PI_D / static_cast<double>(n));
+                        const d3 acc = refl_sum * (HALF_PI_D / static_cast<double>(n));
                         result = result + hadamard(acc, mc);
                     }
                     bool has_refr;
@@ -1024,10 +1044,7 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
                             has_refr = refract_dir(d, s.n, ray_ior / m.refractive_index, &dummy);
                         }
                     }
-                    if (has_refr) {
-                        d3 pass = next_real ? child_rgb(child) : mk3(0.0, 0.0, 0.0);
-                        result = result + pass * (1.0 - m.opacity);
-                    }
+                    if (has_refr) result = result + refr_rgb * (1.0 - m.opacity);
                 }
                 flag = t <= sc.opts.max_occlusion_distance ? 1u : 0u;  // :512-516
             } else {
@@ -1039,9 +1056,7 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
                 if (m.kind == RT_MAT_PHONG) {
                     if (m.reflectivity > 0.0) {  // :184-199
                         has_refl = true;
-                        d3 cc = next_real ? child_rgb(child) : mk3(0.0, 0.0, 0.0);
-                        if (next_real) child += 1;
-                        reflection = hadamard(cc, mc);
+                        reflection = hadamard(refl_sum, mc);
                     }
                 } else {  // :350-411
                     d3 view_dir = unit3(-d);
@@ -1054,10 +1069,7 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
                     if (sc.opts.max_reflected_rays > 0) {
                         has_refl = true;
                         const uint32_t n = refl_rays(sc, level);
-                        for (uint32_t r = 0; r < n; ++r)
-                            reflection = reflection + (next_real ? sat01(child_rgb(child + r)) : mk3(0.0, 0.0, 0.0));
-                        if (next_real) child += n;
-                        reflection = reflection * (HALF_PI_D / static_cast<double>(n));
+                        reflection = refl_sum * (HALF_PI_D / static_cast<double>(n));
                     }
                     if (next_real) {
                         has_refr = nT != 0;
@@ -1067,11 +1079,7 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
                         d3 dummy;
                         has_refr = refract_dir(d, s.n, ray_ior / m.refractive_index, &dummy);
                     }
-                    if (has_refr) {
-                        d3 cc = next_real ? child_rgb(child) : mk3(0.0, 0.0, 0.0);
-                        if (next_real) child += 1;
-                        refraction = hadamard(cc, mix3(mk3(1.0, 1.0, 1.0), f, m.opacity));
-                    }
+                    if (has_refr) refraction = hadamard(refr_rgb, mix3(mk3(1.0, 1.0, 1.0), f, m.opacity));
                 }
                 // ---- direct lighting
                 d3 ambient = mk3(0.0, 0.0, 0.0), irradiance = mk3(0.0, 0.0, 0.0);
@@ -1118,19 +1126,11 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
                     }
                 }
                 // ---- global illumination / ambient occlusion, :98-133
-                const uint32_t nG = gi_rays(sc, level);
-                d3 incoming = mk3(0.0, 0.0, 0.0);
-                uint32_t unoccluded = nG;
-                if (next_real) {
-                    unoccluded = 0;
-                    for (uint32_t g = 0; g < nG; ++g) {
-                        const uint32_t w = np.prim[child + g];
-                        if (w & 2u) incoming = incoming + mk3(np.t[child + g], np.bu[child + g], np.bv[child + g]);  // + 0.0 is exact
-                        if (!(w & 1u)) unoccluded++;
-                    }
-                }
-                incoming = incoming / static_cast<double>(nG);
-                const double ao = static_cast<double>(unoccluded) / static_cast<double>(nG);
+                const uint32_t n_gi = gi_rays(sc, level);  // == nG unless the next level is cut off (then nothing was cast:
+                if (!next_real) unoccluded = n_gi;         //    zero light, every ray unoccluded, :495-497)
+                d3 incoming = gi_sum;
+                incoming = incoming / static_cast<double>(n_gi);
+                const double ao = static_cast<double>(unoccluded) / static_cast<double>(n_gi);
                 const d3 gi_tint = m.kind == RT_MAT_PHONG ? mc : diffuse;
                 d3 color = emissive + (ambient + irradiance + hadamard(incoming, gi_tint)) * ao;
                 if (has_refl) {
