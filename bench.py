@@ -192,6 +192,14 @@ def main():
                 traffic = json.load(open(pmc_path)).get("k_trace_" + kern, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu = None
+        valu_path = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if default_workload and os.path.exists(valu_path):  # SQ_* PMC passes of the same workload (tools/profile_all.sh)
+            try:
+                v = json.load(open(valu_path)).get("k_trace_" + kern, {})
+                valu = {k: v[k] for k in ("valu_busy", "lane_use", "fp64_tflops", "fp64_frac_of_peak", "wait_share") if k in v} or None
+            except Exception:
+                valu = None
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_trace_" + kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -201,6 +209,7 @@ def main():
             "prims_per_ray": round(prims_c if kern == "closest" else prims_s, 2),
             "kernel_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
             "dominant_class": dominant,
+            "valu": valu,  # co-limit: VALU issue occupancy / lane use / FP64 rate of the same kernel, from profiles/pmc_valu.json
             "pipeline_gbs": round((work.closest_rays * bytes_c + work.shadow_rays * bytes_s) / (elapsed / max(1, args.steps)) / 1e9, 2),
         }
         # ---- CPU baseline: the reference's algorithm (kd-tree order) on the host cores, bounded sample
