@@ -417,15 +417,10 @@ template <bool COUNT>
 __device__ __forceinline__ uint32_t descend(const SceneDev &sc, const uint4 *top_nodes, const CullRay &cr, float limit, uint32_t cur,
                                             uint32_t *stack, uint32_t &sp, unsigned long long &n_nodes) {
     while (!(cur & LEAF_FLAG) && cur != STACK_SENTINEL) {
-        uint4 w0, w1;  // the 32-byte node: lmin lmax rmin | rmax left right
-        if (cur < sc.n_top_nodes) {
-            w0 = top_nodes[2u * cur];
-            w1 = top_nodes[2u * cur + 1u];
-        } else {
-            const uint4 *g = reinterpret_cast<const uint4 *>(sc.nodes + cur);
-            w0 = g[0];
-            w1 = g[1];
-        }
+        // the 32-byte node (lmin lmax rmin | rmax left right) through a generic pointer: one pair of 16-byte loads
+        // serves the lanes whose node is in LDS and those whose node is in memory
+        const uint4 *nd = cur < sc.n_top_nodes ? top_nodes + 2u * cur : reinterpret_cast<const uint4 *>(sc.nodes + cur);
+        const uint4 w0 = nd[0], w1 = nd[1];
         if (COUNT) {  // low 40 bits: lane-level visits; high bits: wave-level visits (counted by the first active lane)
             n_nodes++;
             if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(__ballot(true)) - 1)) n_nodes += 1ull << 40;
