@@ -130,6 +130,44 @@ def test_full_size_ray_count(rt, full_scene):
     assert st.ray_count == n == st.closest_rays + st.shadow_rays and st.camera_rays == 800 * 800 * 4
 
 
+PUBLISHED_RAYS = {k: v["published"] for k, v in RAY_COUNTS.items()}
+PUBLISHED_RAYS["mesh_test"] = 41492072  # renders/renders.md:33
+
+
+def _block_mean(img, b=8):
+    h, w, _ = img.shape
+    return img.reshape(h // b, b, w // b, b, 3).mean(axis=(1, 3))
+
+
+# raw (un-denoised, skip_denoise_pass) reference renders: block-mean RMSE bound in 8-bit levels.  Measured on MI355X:
+# test 2.31 (textures: JPEG decoder differences, parity unpinned), mesh 0.16, refraction 0.15, physical 0.26, mesh_test 0.18.
+RAW_RENDERS = {"test": 4.0, "mesh": 0.5, "refraction": 0.5, "physical": 0.6, "mesh_test": 0.5}
+
+
+@pytest.mark.parametrize("name", sorted(PUBLISHED_RAYS))
+def test_full_size_against_the_references_own_outputs(rt, name):
+    """Every scene the reference publishes, at its full 800x800x4spp (BASELINE configs 3 and 4 included): ray count
+    within 0.1 % of renders/renders.md (a 3-run average of a random process) and, where the committed render is raw
+    tracer output, 8x8 block means within a fraction of an 8-bit level of the reference's PNG (its RNG stream is
+    unknown, so per-pixel comparison is meaningless; scene / occlusion / emissive PNGs were OIDN-filtered)."""
+    from PIL import Image
+
+    device, _, _ = rt
+    s = load_scene(name)
+    gpu = device.DeviceScene(s.desc)
+    _, rgba, n, _ = gpu.render()
+    pub = PUBLISHED_RAYS[name]
+    assert abs(n - pub) / pub < 1e-3, (n, pub)
+    if name in RAY_COUNTS:
+        assert abs(n - RAY_COUNTS[name]["oracle_canonical"]) <= max(200, pub // 1000000)
+    if name in RAW_RENDERS:
+        ref = np.array(Image.open(os.path.join(GOLDEN, "renders", f"{name}.png")).convert("RGB")).astype(np.float64)
+        ours = rgba[..., :3].astype(np.float64)
+        d = _block_mean(ours) - _block_mean(ref)
+        assert float(np.sqrt((d ** 2).mean())) < RAW_RENDERS[name]
+        assert abs(ours.mean() - ref.mean()) < 1.0
+
+
 def test_full_size_properties(rt, full_scene):
     """Size-independent properties at the BASELINE size: idempotence, independence
     of the pool budget (batch partition), tile shards and windows compose exactly,
