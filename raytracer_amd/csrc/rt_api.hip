@@ -427,6 +427,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     std::vector<Aabb> boxes;       // reference AABBs (part of the hit predicate)
     std::vector<Aabb> cull_boxes;  // what the BVH is built from
     std::vector<uint32_t> bounded_ids;
+    std::vector<uint32_t> leaf_group;   // per bounded primitive: which primitives it may share a BVH leaf with
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const uint32_t type = d->prim_type[i];
         if (type > RT_PRIM_TRIANGLE) return fail(RT_ERR_INVALID, "bad primitive type");
@@ -509,11 +510,12 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
             cull_boxes.push_back(boxes.back());
         }
         bounded_ids.push_back(i);
+        leaf_group.push_back(type == RT_PRIM_TRIANGLE ? sh.xf : NO_LEAF_GROUP);  // a mesh's faces share its transform
     }
     if (bounded_ids.size() >= (1ull << 28)) return fail(RT_ERR_UNSUPPORTED, "too many bounded primitives");
 
     // ---- BVH
-    BvhBuildResult bvh = build_bvh(cull_boxes);
+    BvhBuildResult bvh = build_bvh(cull_boxes, &leaf_group);
     std::vector<LeafPrim> leaf(bvh.order.size());
     for (size_t j = 0; j < bvh.order.size(); ++j) {
         const uint32_t b = bvh.order[j], pid = bounded_ids[b];

@@ -24,7 +24,11 @@ struct BvhBuildResult {
 
 // boxes: world AABBs of the bounded primitives.  Depth never exceeds
 // STACK_DEPTH - 1 so the per-lane LDS stack of the traversal kernels suffices.
-BvhBuildResult build_bvh(const std::vector<Aabb> &boxes);
+// leaf_group (optional, one entry per box): primitives may share a leaf only when they
+// carry the same group value other than NO_LEAF_GROUP (triangles of one mesh: same
+// object-space ray, same code path); everything else gets a leaf of its own.
+constexpr uint32_t NO_LEAF_GROUP = 0xFFFFFFFFu;
+BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint32_t> *leaf_group = nullptr);
 
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) {
     return LEAF_FLAG | ((count - 1u) << 28) | first;
