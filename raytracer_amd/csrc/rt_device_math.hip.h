@@ -297,6 +297,14 @@ __device__ __forceinline__ bool hit_bounded(const double *__restrict__ g, uint32
         n2 = dot3(r.d, qv);
         n3 = dot3(e2, qv);
         q_d1 = q_d2 = q_d3 = det;
+        // Certain misses leave before the divisions (a mesh triangle's box is hit 20-30 times more often than the
+        // triangle; when every lane of the wave leaves here the division block is skipped).  With a = n * sign(det)
+        // and m = |det|, IEEE division gives: a < 0 beyond underflow => n / det < 0; a1 > m => u > 1; and
+        // a1 + a2 > m (1 + 1e-9) with both non-negative => u + v > 1 whatever the three roundings do.  Anything
+        // near a boundary (and every NaN: all comparisons false) goes on to the reference's own arithmetic.
+        const double m = fabs(det), sgn = det < 0.0 ? -1.0 : 1.0;
+        const double a1 = n1 * sgn, a2 = n2 * sgn, a3 = n3 * sgn, floor_ = -1e-300 * m;
+        if (a1 < floor_ || a2 < floor_ || a3 < floor_ || a1 > m || a1 + a2 > m * (1.0 + 1e-9)) return false;
     } else if (type == RT_PRIM_SPHERE) {
         const double radius = g[0];
         const double ray_proj = dot3(r.o, r.d);
