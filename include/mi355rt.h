@@ -208,6 +208,23 @@ int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes);
 int rt_render_device(rt_scene *scene, const rt_render_params *params, double *d_rgb_accum,
                      uint64_t *ray_count, rt_render_stats *stats, void *stream);
 
+/* As rt_render_device, plus the other two members of the ColorData that screen_raycast returns
+ * (src/render/mod.rs:16-20, src/render/raytracing_scene.rs:598-622), which the reference hands to its
+ * denoise pass (:645-701):
+ *   d_albedo_accum[(y*width+x)*3 + c] += sum over the samples of the clamped albedo (:543, :610); the
+ *       final albedo is clamp(accum * (1/spp)) (:616, :619);
+ *   d_normal[(y*width+x)*3 + c] = normal of sample 0's ColorData (:603-605): the shading normal of the
+ *       first hit, or the normal at the end of its refraction chain (:485), (0,0,1) for a miss
+ *       (ColorData::black, mod.rs:39-41).  Written only when the sample range contains sample 0.
+ * Both are DEVICE pointers to w*h*3 doubles; either may be NULL. */
+int rt_render_aov_device(rt_scene *scene, const rt_render_params *params, double *d_rgb_accum, double *d_albedo_accum,
+                         double *d_normal, uint64_t *ray_count, rt_render_stats *stats, void *stream);
+
+/* Host-pointer convenience for the AOVs: zero-initialised accumulation, render, copy back.  rgb_accum, albedo
+ * (FINAL: clamp(sum * (1/spp))) and normal are w*h*3 doubles each and may be NULL. */
+int rt_render_aov(rt_scene *scene, const rt_render_params *params, double *rgb_accum, double *albedo, double *normal,
+                  uint64_t *ray_count, rt_render_stats *stats);
+
 /* Replaces :614-621 + :757-769: colour = accum / spp, clamp, ^(1/2.2),
  * (c*255.0) as u8, alpha 255.  Both pointers are DEVICE pointers. */
 int rt_tonemap_device(rt_scene *scene, const double *d_rgb_accum, uint8_t *d_rgba8, void *stream);

@@ -34,6 +34,8 @@ def lib():
         l.orc_scene_info.argtypes = [vp, C.POINTER(C.c_uint64)]
         l.orc_render.argtypes = [vp, C.c_int, vp, C.c_int, f64p, u8p, C.POINTER(C.c_uint64)]
         l.orc_render.restype = C.c_int
+        l.orc_render_aov.argtypes = [vp, C.c_int, vp, C.c_int, f64p, f64p, f64p, u8p, C.POINTER(C.c_uint64)]
+        l.orc_render_aov.restype = C.c_int
         l.orc_query_primary.argtypes = [vp, C.c_int, u32p, f64p, f64p]
         l.orc_query_primary.restype = C.c_int
         l.orc_trace_rays.argtypes = [vp, C.c_int, C.c_uint32, f64p, f64p, f64p, C.c_int, u32p, f64p]
@@ -108,6 +110,23 @@ class OracleScene:
             )
         )
         return acc, rgba, int(count.value)
+
+    def render_aov(self, params=None, mode=MODE_KD, threads=None):
+        """-> (rgb_sum, albedo_sum, normal[h,w,3], ray_count): ColorData's three members per pixel (render/mod.rs:16-20)."""
+        from raytracer_amd._abi import RenderParams
+
+        params = params or RenderParams()
+        threads = threads or min(os.cpu_count() or 1, 16)
+        shape = (self.height, self.width, 3)
+        acc, alb, nrm = np.zeros(shape, np.float64), np.zeros(shape, np.float64), np.zeros(shape, np.float64)
+        count = C.c_uint64(0)
+        _check(
+            lib().orc_render_aov(
+                self._h, mode, C.cast(C.byref(params), C.c_void_p), threads, _p(acc, C.c_double), _p(alb, C.c_double),
+                _p(nrm, C.c_double), None, C.byref(count),
+            )
+        )
+        return acc, alb, nrm, int(count.value)
 
     def query_primary(self, mode=MODE_CANONICAL):
         n = self.width * self.height

@@ -1292,15 +1292,20 @@ struct Integrator {
         return Ray{RAY_PRIMARY, 0, v3(sc.camera.position[0], sc.camera.position[1], sc.camera.position[2]), wd, 1.0};
     }
 
-    // Sum over samples [s0,s1) of the clamped colour (:605-612, before the 1/spp).
-    V3 pixel_sum(uint32_t x, uint32_t y, uint32_t s0, uint32_t s1) {
-        V3 sum = v3(0, 0, 0);
+    // Sum over samples [s0,s1) of the clamped colour (:605-612, before the 1/spp); optionally the other two members
+    // of ColorData as screen_raycast carries them: the sum of the clamped albedos (:610) and the normal of sample 0
+    // (:603-605: the pixel's ColorData starts as the first ray's).
+    V3 pixel_sum(uint32_t x, uint32_t y, uint32_t s0, uint32_t s1, V3 *albedo_sum = nullptr, V3 *normal0 = nullptr) {
+        V3 sum = v3(0, 0, 0), alb = v3(0, 0, 0);
         for (uint32_t s = s0; s < s1; ++s) {
             rng.pixel = y * sc.opts.width + x;
             rng.sample = s;
             ColorData cd = get_color(camera_ray(x, y, s), 0);
             sum = s == s0 ? cd.color : sum + cd.color;
+            alb = s == s0 ? cd.albedo : alb + cd.albedo;
+            if (s == 0 && normal0) *normal0 = cd.normal;
         }
+        if (albedo_sum) *albedo_sum = alb;
         return sum;
     }
 };
@@ -1481,8 +1486,18 @@ int orc_scene_info(const orc_scene *s, uint64_t *out6) {
 // Same contract as rt_render (mi355rt.h) with host buffers; rgb_accum is
 // += accumulated, rgba8 is produced from rgb_accum (or the call's own sums when
 // rgb_accum is NULL) for the pixels of the window.
+int orc_render_aov(const orc_scene *s, int mode, const rt_render_params *params, int n_threads, double *rgb_accum,
+                   double *albedo_accum, double *normal, uint8_t *rgba8, uint64_t *ray_count);
+
 int orc_render(const orc_scene *s, int mode, const rt_render_params *params, int n_threads, double *rgb_accum,
                uint8_t *rgba8, uint64_t *ray_count) {
+    return orc_render_aov(s, mode, params, n_threads, rgb_accum, nullptr, nullptr, rgba8, ray_count);
+}
+
+// As orc_render, plus the AOVs of ColorData (render/mod.rs:16-20): albedo_accum[w*h*3] += sum over the samples of the
+// clamped albedo; normal[w*h*3] = normal of sample 0 (written only when the sample range contains sample 0).
+int orc_render_aov(const orc_scene *s, int mode, const rt_render_params *params, int n_threads, double *rgb_accum,
+                   double *albedo_accum, double *normal, uint8_t *rgba8, uint64_t *ray_count) {
     if (!s || !params) {
         g_error = "null argument";
         return RT_ERR_INVALID;
@@ -1518,11 +1533,22 @@ int orc_render(const orc_scene *s, int mode, const rt_render_params *params, int
             uint32_t y = next_row.fetch_add(1);
             if (y >= y1) break;
             for (uint32_t x = x0; x < x1; ++x) {
-                V3 sum = integ.pixel_sum(x, y, s0, s1);
+                V3 alb, nrm = v3(0, 0, 1);
+                V3 sum = integ.pixel_sum(x, y, s0, s1, &alb, &nrm);
                 size_t o = (static_cast<size_t>(y) * w + x) * 3;
                 acc[o] += sum.x;
                 acc[o + 1] += sum.y;
                 acc[o + 2] += sum.z;
+                if (albedo_accum) {
+                    albedo_accum[o] += alb.x;
+                    albedo_accum[o + 1] += alb.y;
+                    albedo_accum[o + 2] += alb.z;
+                }
+                if (normal && s0 == 0) {
+                    normal[o] = nrm.x;
+                    normal[o + 1] = nrm.y;
+                    normal[o + 2] = nrm.z;
+                }
             }
         }
         total += integ.ray_count;

@@ -664,7 +664,13 @@ int rt_scene_info(rt_scene *scene, uint64_t *out8) {
 
 int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_accum, uint64_t *ray_count,
                      rt_render_stats *stats, void *stream_v) {
+    return rt_render_aov_device(s, params, d_rgb_accum, nullptr, nullptr, ray_count, stats, stream_v);
+}
+
+int rt_render_aov_device(rt_scene *s, const rt_render_params *params, double *d_rgb_accum, double *d_albedo_accum,
+                         double *d_normal, uint64_t *ray_count, rt_render_stats *stats, void *stream_v) {
     if (!s || !d_rgb_accum) return fail(RT_ERR_INVALID, "null argument");
+    const uint32_t aov = (d_albedo_accum || d_normal) ? 1u : 0u;
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     int rc = ensure_pools(s);
     if (rc) return rc;
@@ -737,13 +743,13 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
             for (uint32_t level = max_depth; level-- > 0;) {
                 timer.begin(CLS_RESOLVE);
                 const dim3 gr(level == 0 ? shard_grid(s, sh, n, 8) : g_wide);
-                if (level > 0) hipLaunchKernelGGL(k_resolve<true>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, level);  // camera rays are colour nodes
-                hipLaunchKernelGGL(k_resolve<false>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, level);
+                if (level > 0) hipLaunchKernelGGL(k_resolve<true>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, level, 0u);  // camera rays are colour nodes
+                hipLaunchKernelGGL(k_resolve<false>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, level, aov);
                 timer.end();
             }
             timer.begin(CLS_ACCUM);
             hipLaunchKernelGGL(k_accumulate, dim3(shard_grid(s, sh, n / wl.ns, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, s->d_ctr, sh,
-                               d_rgb_accum);
+                               d_rgb_accum, d_albedo_accum, d_normal);
             timer.end();
         }
         HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, sh.count * sizeof(Counters), hipMemcpyDeviceToHost, stream));
@@ -842,6 +848,40 @@ int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_
     }
     if (ray_count) *ray_count += st.ray_count;
     return RT_OK;
+}
+
+int rt_render_aov(rt_scene *s, const rt_render_params *params, double *rgb_accum, double *albedo, double *normal,
+                  uint64_t *ray_count, rt_render_stats *stats) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    const uint64_t n3 = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height * 3;
+    const double inv_spp = 1.0 / static_cast<double>(s->dev.opts.samples_per_pixel);
+    double *d_buf = nullptr;  // [rgb | albedo | normal]
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_buf), 3 * n3 * sizeof(double)));
+    int rc = RT_OK;
+    do {
+        if (hipMemset(d_buf, 0, 3 * n3 * sizeof(double)) != hipSuccess) {
+            rc = fail(RT_ERR_DEVICE, "hipMemset failed");
+            break;
+        }
+        if ((rc = rt_render_aov_device(s, params, d_buf, albedo ? d_buf + n3 : nullptr, normal ? d_buf + 2 * n3 : nullptr, ray_count,
+                                       stats, nullptr)))
+            break;
+        hipError_t e = hipSuccess;
+        if (rgb_accum) e = hipMemcpy(rgb_accum, d_buf, n3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && albedo) e = hipMemcpy(albedo, d_buf + n3, n3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && normal) e = hipMemcpy(normal, d_buf + 2 * n3, n3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            rc = fail(RT_ERR_DEVICE, std::string("rt_render_aov: ") + hipGetErrorString(e));
+            break;
+        }
+        if (albedo && s->dev.opts.samples_per_pixel != 1)  // :616 `albedo *= inv_samples`, :619 clamp (one sample: get_color's own clamp)
+            for (uint64_t i = 0; i < n3; ++i) {
+                const double a = albedo[i] * inv_spp;
+                albedo[i] = a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);
+            }
+    } while (false);
+    hipFree(d_buf);
+    return rc;
 }
 
 int rt_tonemap_device(rt_scene *s, const double *d_rgb_accum, uint8_t *d_rgba8, void *stream_v) {

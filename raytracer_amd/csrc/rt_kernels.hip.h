@@ -951,7 +951,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
 // illumination nodes do not run at the colour path's two waves per SIMD.
 template <bool ILLUM>
 __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
-                                                  uint32_t level) {
+                                                  uint32_t level, uint32_t aov) {
     __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
     __shared__ LevelMap map;
     const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
@@ -1135,6 +1135,23 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
                 }
                 if (has_refr) color = mix3(sat01(refraction), color, m.opacity);                      // :481-486
                 result = sat01(color);                                                                  // :543
+                // The other two members of this node's ColorData, for the nodes whose ColorData somebody reads: camera
+                // rays (screen_raycast) and refraction children (:485 `normal = refraction.normal`).  They go where the
+                // ray was (nobody reads it again): (albedo | normal) over r0 r1 r2.
+                if (aov && (level == 0 || (meta & META_REFR))) {
+                    d3 n_out = s.n;
+                    if (has_refr) {
+                        n_out = mk3(0.0, 0.0, 1.0);  // ColorData::black of a miss or of the depth cut-off (mod.rs:39-41)
+                        if (next_real) {
+                            const uint32_t rc = xi.first_child + nR;  // the refraction child follows the reflections
+                            if (!(np.meta[rc] & META_DONE)) {         // a colour node is finished by the trace kernel only as a miss
+                                const Vec2d b = np.r1[rc], c = np.r2[rc];
+                                n_out = mk3(b.y, c.x, c.y);
+                            }
+                        }
+                    }
+                    store_ray(np, idx, sat01(mc), n_out);  // :543 clamps the albedo too
+                }
             }
         }
         if (!(result.x == 0.0 && result.y == 0.0 && result.z == 0.0)) {  // NaN counts as non-zero
@@ -1150,7 +1167,7 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(Sc
 // ------------------------------------------------------------------ accumulate / tonemap / AOVs
 // screen_raycast :605-612: sum of the per-sample clamped colours, in sample order.
 __global__ __launch_bounds__(BLOCK) void k_accumulate(SceneDev sc, WorkList wl, NodePool np, Counters *ctrs, Shards shards,
-                                                     double *accum) {
+                                                     double *accum, double *albedo_accum, double *normal_out) {
     for (uint32_t k = 0; k < shards.count; ++k)  // += semantics: nothing may land if the batch is going to be re-run
         if (ctrs[k].overflow) return;
     const ShardCtx c = shard_ctx(ctrs, shards);
@@ -1167,6 +1184,28 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(SceneDev sc, WorkList wl, 
         accum[at] += sum.x;
         accum[at + 1] += sum.y;
         accum[at + 2] += sum.z;
+        // AOVs (k_resolve left albedo | normal in the camera nodes' ray fields; a node the trace kernel finished is a miss)
+        if (albedo_accum) {  // :610, in sample order
+            d3 alb = mk3(0.0, 0.0, 0.0);
+            for (uint32_t s = 0; s < wl.ns; ++s)
+                if (!(np.meta[node0 + s] & META_DONE)) {
+                    const Vec2d a = np.r0[node0 + s], b = np.r1[node0 + s];
+                    alb = alb + mk3(a.x, a.y, b.x);
+                }
+            albedo_accum[at] += alb.x;
+            albedo_accum[at + 1] += alb.y;
+            albedo_accum[at + 2] += alb.z;
+        }
+        if (normal_out && wl.s0 == 0) {  // the pixel's ColorData starts as sample 0's (:603-605)
+            d3 n = mk3(0.0, 0.0, 1.0);
+            if (!(np.meta[node0] & META_DONE)) {
+                const Vec2d b = np.r1[node0], cc = np.r2[node0];
+                n = mk3(b.y, cc.x, cc.y);
+            }
+            normal_out[at] = n.x;
+            normal_out[at + 1] = n.y;
+            normal_out[at + 2] = n.z;
+        }
     }
 }
 

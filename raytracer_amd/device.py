@@ -14,7 +14,7 @@ _LIB = None
 
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_set_pool_bytes", "rt_render_device", "rt_tonemap_device",
-    "rt_render", "rt_query_primary", "rt_trace_rays", "rt_scene_info", "rt_last_error", "rt_version",
+    "rt_render", "rt_render_aov_device", "rt_render_aov", "rt_query_primary", "rt_trace_rays", "rt_scene_info", "rt_last_error", "rt_version",
 ]
 
 
@@ -55,6 +55,10 @@ def lib():
         l.rt_scene_set_pool_bytes.restype = C.c_int
         l.rt_render_device.argtypes = [vp, C.POINTER(_abi.RenderParams), vp, u64p, C.POINTER(_abi.RenderStats), vp]
         l.rt_render_device.restype = C.c_int
+        l.rt_render_aov_device.argtypes = [vp, C.POINTER(_abi.RenderParams), vp, vp, vp, u64p, C.POINTER(_abi.RenderStats), vp]
+        l.rt_render_aov_device.restype = C.c_int
+        l.rt_render_aov.argtypes = [vp, C.POINTER(_abi.RenderParams), f64p, f64p, f64p, u64p, C.POINTER(_abi.RenderStats)]
+        l.rt_render_aov.restype = C.c_int
         l.rt_tonemap_device.argtypes = [vp, vp, vp, vp]
         l.rt_tonemap_device.restype = C.c_int
         l.rt_render.argtypes = [vp, C.POINTER(_abi.RenderParams), f64p, u8p, u64p, C.POINTER(_abi.RenderStats)]
@@ -111,6 +115,25 @@ class DeviceScene:
             )
         )
         return acc, rgba, int(count.value), stats
+
+    def render_aov(self, params=None):
+        """ColorData's three members per pixel (src/render/mod.rs:16-20) ->
+        (rgb_sum[h,w,3], albedo[h,w,3] final = clamp(sum/spp), normal[h,w,3] of sample 0, ray_count)."""
+        params = params or _abi.RenderParams()
+        shape = (self.height, self.width, 3)
+        acc, alb, nrm = np.zeros(shape, np.float64), np.zeros(shape, np.float64), np.zeros(shape, np.float64)
+        count = C.c_uint64(0)
+        _check(lib().rt_render_aov(self._h, C.byref(params), _p(acc, C.c_double), _p(alb, C.c_double), _p(nrm, C.c_double),
+                                   C.byref(count), None))
+        return acc, alb, nrm, int(count.value)
+
+    def render_aov_device(self, d_accum_ptr, d_albedo_ptr, d_normal_ptr, params=None, stream=None):
+        """Device-buffer form: albedo is the SUM over samples (+= semantics), normal is sample 0's."""
+        params = params or _abi.RenderParams()
+        count = C.c_uint64(0)
+        _check(lib().rt_render_aov_device(self._h, C.byref(params), C.c_void_p(d_accum_ptr), C.c_void_p(d_albedo_ptr or 0),
+                                          C.c_void_p(d_normal_ptr or 0), C.byref(count), None, C.c_void_p(stream or 0)))
+        return int(count.value)
 
     def render_device(self, d_accum_ptr, params=None, stream=None, want_stats=True):
         """Device-buffer render: d_accum_ptr is a device address (int) of w*h*3 doubles."""

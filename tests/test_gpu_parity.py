@@ -300,6 +300,44 @@ def test_device_buffers_and_tonemap_with_torch(rt):
     assert np.allclose(acc.cpu().numpy(), 2 * acc_c, atol=1e-9)
 
 
+@pytest.mark.parametrize("name,size,spp", [("test", 64, 4), ("refraction", 96, 4), ("physical", 64, 2), ("scene", 96, 4),
+                                           ("cornell_box", 48, 1), ("mesh", 64, 3)])
+def test_aovs_match_oracle(rt, name, size, spp):
+    """The other two members of screen_raycast's ColorData (src/render/mod.rs:16-20): albedo = clamp(mean over the
+    samples of the clamped material colour of the first hit) and the normal of sample 0 -- which follows the refraction
+    chain (:485; refraction.json) and is (0,0,1) on a miss.  The colour must not change when AOVs are asked for."""
+    device, ob, abi = rt
+    s = load_scene(name, size=size, spp=spp)
+    gpu, cpu = device.DeviceScene(s.desc), ob.OracleScene(s.desc)
+    acc_g, alb_g, nrm_g, n_g = gpu.render_aov()
+    acc_c, alb_sum_c, nrm_c, n_c = cpu.render_aov(mode=ob.MODE_CANONICAL, threads=16)
+    acc_plain, _, n_plain, _ = gpu.render(want_rgba=False)
+    assert n_g == n_plain and np.array_equal(acc_g, acc_plain)
+    assert abs(n_g - n_c) <= max(2, n_c // 100000)
+    alb_c = alb_sum_c if spp == 1 else np.clip(alb_sum_c * (1.0 / spp), 0.0, 1.0)
+    ids_c, _, _ = cpu.query_primary(ob.MODE_CANONICAL)
+    tie = 0.03 if name == "cornell_box" else 0.0  # coplanar light / ceiling (quirk Q17)
+    assert (np.abs(alb_g - alb_c).max(axis=2) > 1e-12).mean() <= tie
+    assert (np.abs(nrm_g - nrm_c).max(axis=2) > REL_TOL).mean() <= tie
+    miss = ids_c == NO_HIT
+    assert np.array_equal(nrm_g[miss], np.broadcast_to([0.0, 0.0, 1.0], nrm_g[miss].shape))  # sample 0 is the pixel centre
+    assert np.allclose(np.linalg.norm(nrm_g, axis=2), 1.0, atol=1e-12)
+    # sample ranges compose: albedo sums add up, the normal comes with sample 0 only
+    if spp > 1:
+        import torch
+
+        bufs = torch.zeros((3, size, size, 3), dtype=torch.float64, device="cuda:0")
+        ptr = lambda i: bufs[i].data_ptr()
+        torch.cuda.synchronize()
+        gpu.render_aov_device(ptr(0), ptr(1), ptr(2), abi.RenderParams(s0=1, s1=spp))
+        torch.cuda.synchronize()
+        assert not bufs[2].any()
+        gpu.render_aov_device(ptr(0), ptr(1), ptr(2), abi.RenderParams(s0=0, s1=1))
+        torch.cuda.synchronize()
+        assert np.allclose(bufs[1].cpu().numpy(), alb_sum_c, atol=1e-12)
+        assert np.allclose(bufs[2].cpu().numpy(), nrm_g, atol=0)
+
+
 def test_work_counters(rt):
     """RT_FLAG_COUNT_WORK feeds bench.py's roofline: nodes visited / primitives tested per ray."""
     device, _, abi = rt

@@ -247,3 +247,19 @@ def test_window_and_sample_ranges_compose(libs):
     a0, _, c0 = o.render(RenderParams(s0=0, s1=1), mode=ob.MODE_CANONICAL, threads=4, want_rgba=False)
     a1, _, c1 = o.render(RenderParams(s0=1, s1=4), mode=ob.MODE_CANONICAL, threads=4, want_rgba=False)
     assert c0 + c1 == n_full and np.allclose(a0 + a1, full, rtol=0, atol=1e-12)
+
+
+def test_oracle_aovs_are_consistent(libs):
+    """ColorData's albedo / normal members (render/mod.rs:16-20) as the oracle reports them: the colour is the one
+    orc_render gives, the normal of a non-refractive first hit is the primary-hit normal, (0,0,1) on a miss."""
+    _, ob = libs
+    s = load_scene("test", size=48)
+    o = ob.OracleScene(s.desc)
+    acc, alb, nrm, n = o.render_aov(mode=ob.MODE_CANONICAL, threads=4)
+    acc2, _, n2 = o.render(mode=ob.MODE_CANONICAL, threads=4, want_rgba=False)
+    assert n == n2 and np.array_equal(acc, acc2)
+    ids, _, n0 = o.query_primary(ob.MODE_CANONICAL)
+    miss = ids == 0xFFFFFFFF
+    assert np.array_equal(nrm[miss], np.broadcast_to([0.0, 0.0, 1.0], nrm[miss].shape))
+    assert np.array_equal(nrm[~miss], n0[~miss])  # test.json has no refractive material
+    assert alb.min() >= 0.0 and alb.max() <= s.opts.samples_per_pixel and alb[~miss].any()
