@@ -5,7 +5,9 @@
 #include "rt_bvh.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <utility>
 #include <limits>
 
@@ -33,13 +35,32 @@ float round_up(double x) {
     return f;
 }
 
+// Nodes of one subtree, numbered from 0.  The top of the tree and every subtree job build into an arena of their own;
+// the arenas are then laid end to end (interior refs shifted) -- and the breadth-first renumbering at the end makes
+// the final numbering independent of how the work was cut up, so the tree is the same for any thread count.
+struct Arena {
+    std::vector<BvhNode> nodes;
+    std::vector<std::pair<Aabb, Aabb>> child_boxes;  // exact f64 child boxes per node
+    uint32_t max_depth = 0, n_leaves = 0;
+};
+constexpr uint32_t JOB_FLAG = 0x40000000u;  // temporary child ref of the top arena: bits 0..29 = subtree job (no node index reaches 2^28)
+
 struct Builder {
     const std::vector<Aabb> &boxes;
     const std::vector<uint32_t> *leaf_group = nullptr;
     std::vector<uint32_t> order;
     std::vector<double> cx, cy, cz;
     BvhBuildResult out;
-    std::vector<std::pair<Aabb, Aabb>> child_boxes;  // exact f64 child boxes per node
+    std::vector<std::pair<Aabb, Aabb>> child_boxes;  // exact f64 child boxes per node (after the arenas are merged)
+    struct Job {
+        uint32_t first, count, depth;
+        Arena arena;
+        uint32_t root_ref = 0;
+        Aabb box{};
+    };
+    std::vector<Job> jobs;
+    uint32_t max_threads = 0;
+    uint32_t job_size = 0xFFFFFFFFu;  // subtrees of at most this many primitives become jobs (top-level build only)
 
     explicit Builder(const std::vector<Aabb> &b) : boxes(b) {}
 
@@ -70,6 +91,8 @@ struct Builder {
         return d;
     }
 
+    uint32_t worker_count() const { return max_threads ? max_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency())); }
+
     // largest leaf the primitives order[first .. first+count) may form
     uint32_t leaf_target(uint32_t first, uint32_t count) const {
         if (count <= 1 || !leaf_group || count > kMeshLeaf) return 1;
@@ -80,8 +103,14 @@ struct Builder {
         return kMeshLeaf;
     }
 
-    // returns child ref, fills box
-    uint32_t build(uint32_t first, uint32_t count, uint32_t depth, Aabb *box_out) {
+    // returns child ref (arena-local), fills box.  TOP: building the top of the tree -- ranges of at most job_size
+    // primitives are not descended into but queued as jobs (their box is filled in when the job has run).
+    template <bool TOP>
+    uint32_t build(uint32_t first, uint32_t count, uint32_t depth, Aabb *box_out, Arena &out) {
+        if (TOP && count <= job_size && count > MAX_LEAF_PRIMS) {
+            jobs.push_back(Job{first, count, depth, Arena{}, 0u, Aabb{}});
+            return JOB_FLAG | static_cast<uint32_t>(jobs.size() - 1);
+        }
         const uint32_t kLeafTarget = leaf_target(first, count);
         Aabb box = empty_box(), cbox = empty_box();
         for (uint32_t i = first; i < first + count; ++i) {
@@ -117,12 +146,41 @@ struct Builder {
                 uint32_t bin_count[kBins] = {0};
                 Aabb bin_box[kBins];
                 for (auto &b : bin_box) b = empty_box();
-                for (uint32_t i = first; i < first + count; ++i) {
-                    uint32_t p = order[i];
-                    int b = static_cast<int>((centroid(p, axis) - lo) * scale);
-                    b = std::min(std::max(b, 0), kBins - 1);
-                    bin_count[b]++;
-                    grow(bin_box[b], boxes[p]);
+                auto bin_chunk = [&](uint32_t a, uint32_t e, uint32_t *cnt, Aabb *bx) {
+                    for (uint32_t i = a; i < e; ++i) {
+                        uint32_t p = order[i];
+                        int b = static_cast<int>((centroid(p, axis) - lo) * scale);
+                        b = std::min(std::max(b, 0), kBins - 1);
+                        cnt[b]++;
+                        grow(bx[b], boxes[p]);
+                    }
+                };
+                const uint32_t workers = (TOP && count >= 262144) ? worker_count() : 1u;
+                if (workers == 1) {
+                    bin_chunk(first, first + count, bin_count, bin_box);
+                } else {  // top of a large tree (serial otherwise, and 7 levels deep before the subtree jobs start):
+                          // chunks binned by the workers, merged -- counts are integers, boxes min/max: same bins
+                    struct Part {
+                        uint32_t cnt[kBins];
+                        Aabb bx[kBins];
+                    };
+                    std::vector<Part> part(workers);
+                    std::vector<std::thread> pool;
+                    const uint32_t step = (count + workers - 1) / workers;
+                    for (uint32_t t = 0; t < workers; ++t) {
+                        for (int b = 0; b < kBins; ++b) {
+                            part[t].cnt[b] = 0;
+                            part[t].bx[b] = empty_box();
+                        }
+                        const uint32_t a = first + std::min(count, t * step), e = first + std::min(count, (t + 1) * step);
+                        pool.emplace_back([&bin_chunk, &part, t, a, e]() { bin_chunk(a, e, part[t].cnt, part[t].bx); });
+                    }
+                    for (auto &th : pool) th.join();
+                    for (const Part &pt : part)
+                        for (int b = 0; b < kBins; ++b) {
+                            bin_count[b] += pt.cnt[b];
+                            grow(bin_box[b], pt.bx[b]);
+                        }
                 }
                 double right_area[kBins];
                 uint32_t right_count[kBins];
@@ -189,23 +247,93 @@ struct Builder {
 
         uint32_t self = static_cast<uint32_t>(out.nodes.size());
         out.nodes.emplace_back();
-        child_boxes.emplace_back();
-        Aabb lb, rb;
-        uint32_t l = build(first, mid - first, depth + 1, &lb);
-        uint32_t r = build(mid, first + count - mid, depth + 1, &rb);
+        out.child_boxes.emplace_back();
+        Aabb lb{}, rb{};
+        uint32_t l = build<TOP>(first, mid - first, depth + 1, &lb, out);
+        uint32_t r = build<TOP>(mid, first + count - mid, depth + 1, &rb, out);
         BvhNode &n = out.nodes[self];
         n.left = l;
         n.right = r;
-        child_boxes[self] = {lb, rb};  // quantised once the root box (= the frame) is known
+        out.child_boxes[self] = {lb, rb};  // quantised once the root box (= the frame) is known
         return self;
+    }
+
+    // Whole tree: top serially, subtree jobs on `threads` workers, arenas merged into this->out / child_boxes.
+    void build_all(uint32_t n, Aabb *root_box) {
+        const uint32_t threads = worker_count();
+        // the cut into jobs depends on n alone, never on the thread count (small scenes: one arena)
+        job_size = n >= 65536 ? std::max<uint32_t>(4096, n / 128) : 0u;
+        Arena top;
+        uint32_t root = job_size ? build<true>(0, n, 0, root_box, top) : build<false>(0, n, 0, root_box, top);
+        if (!jobs.empty()) {
+            std::atomic<uint32_t> next{0};
+            auto work = [&]() {
+                for (uint32_t j; (j = next.fetch_add(1)) < jobs.size();) {
+                    Job &job = jobs[j];
+                    job.root_ref = build<false>(job.first, job.count, job.depth, &job.box, job.arena);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(work);
+            work();
+            for (auto &t : pool) t.join();
+        }
+        // ---- merge: top arena first, then the jobs' arenas in job order
+        std::vector<uint32_t> base(jobs.size());
+        uint32_t total = static_cast<uint32_t>(top.nodes.size());
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            base[j] = total;
+            total += static_cast<uint32_t>(jobs[j].arena.nodes.size());
+        }
+        auto job_ref = [&](uint32_t ref) {  // temporary ref -> final ref of the job's root
+            const uint32_t j = ref & ~JOB_FLAG;
+            const uint32_t r = jobs[j].root_ref;
+            return (r & LEAF_FLAG) ? r : r + base[j];
+        };
+        this->out.nodes.reserve(total);
+        child_boxes.reserve(total);
+        for (size_t i = 0; i < top.nodes.size(); ++i) {
+            BvhNode nd = top.nodes[i];
+            std::pair<Aabb, Aabb> cb = top.child_boxes[i];
+            if (!(nd.left & LEAF_FLAG) && (nd.left & JOB_FLAG)) {
+                cb.first = jobs[nd.left & ~JOB_FLAG].box;
+                nd.left = job_ref(nd.left);
+            }
+            if (!(nd.right & LEAF_FLAG) && (nd.right & JOB_FLAG)) {
+                cb.second = jobs[nd.right & ~JOB_FLAG].box;
+                nd.right = job_ref(nd.right);
+            }
+            this->out.nodes.push_back(nd);
+            child_boxes.push_back(cb);
+        }
+        this->out.max_depth = top.max_depth;
+        this->out.n_leaves = top.n_leaves;
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            const Arena &a = jobs[j].arena;
+            for (size_t i = 0; i < a.nodes.size(); ++i) {
+                BvhNode nd = a.nodes[i];
+                if (!(nd.left & LEAF_FLAG)) nd.left += base[j];
+                if (!(nd.right & LEAF_FLAG)) nd.right += base[j];
+                this->out.nodes.push_back(nd);
+                child_boxes.push_back(a.child_boxes[i]);
+            }
+            this->out.max_depth = std::max(this->out.max_depth, a.max_depth);
+            this->out.n_leaves += a.n_leaves;
+        }
+        if (!(root & LEAF_FLAG) && (root & JOB_FLAG)) {  // the whole scene was one job
+            *root_box = jobs[root & ~JOB_FLAG].box;
+            root = job_ref(root);
+        }
+        this->out.root_ref = root;
     }
 };
 
 }  // namespace
 
-BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint32_t> *leaf_group) {
+BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint32_t> *leaf_group, uint32_t max_threads) {
     Builder b(boxes);
     b.leaf_group = leaf_group;
+    b.max_threads = max_threads;
     const uint32_t n = static_cast<uint32_t>(boxes.size());
     if (n == 0) return std::move(b.out);
     b.order.resize(n);
@@ -218,9 +346,8 @@ BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint3
         b.cy[i] = 0.5 * (boxes[i].mn[1] + boxes[i].mx[1]);
         b.cz[i] = 0.5 * (boxes[i].mn[2] + boxes[i].mx[2]);
     }
-    b.out.nodes.reserve(n);
-    Aabb root;
-    b.out.root_ref = b.build(0, n, 0, &root);
+    Aabb root{};
+    b.build_all(n, &root);
     b.out.root_box = root;
     b.out.order = std::move(b.order);
     // ---- quantisation frame: the root box, 65535 steps per axis

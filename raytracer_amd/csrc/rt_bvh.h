@@ -28,7 +28,9 @@ struct BvhBuildResult {
 // carry the same group value other than NO_LEAF_GROUP (triangles of one mesh: same
 // object-space ray, same code path); everything else gets a leaf of its own.
 constexpr uint32_t NO_LEAF_GROUP = 0xFFFFFFFFu;
-BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint32_t> *leaf_group = nullptr);
+// max_threads: workers for the subtree jobs of a large scene (0 = the host's cores, at most 16); the tree does not
+// depend on it.
+BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint32_t> *leaf_group = nullptr, uint32_t max_threads = 0);
 
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) {
     return LEAF_FLAG | ((count - 1u) << 28) | first;
