@@ -352,6 +352,12 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(SceneDev sc, WorkList wl, Node
 // AABB, so the conservative node test has already pre-filtered it (no divisions,
 // running t limit applied); then the primitive test, and only for primitive
 // hits the reference-order AABB arithmetic (6 divisions).
+#ifndef EXPAND_WAVES
+#define EXPAND_WAVES 4
+#endif
+#ifndef RESOLVE_ILLUM_WAVES
+#define RESOLVE_ILLUM_WAVES 4
+#endif
 #ifndef RESOLVE_WAVES
 #define RESOLVE_WAVES 2
 #endif
@@ -747,7 +753,7 @@ __device__ __forceinline__ uint32_t wave_owner(const uint32_t *incl, uint32_t j)
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, Counters *ctrs,
+__global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, Counters *ctrs,
                                                  Shards shards, uint32_t level) {
     __shared__ ExpandLds L;
     __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
@@ -950,7 +956,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(SceneDev sc, WorkList wl, Node
 // few multiplies) and colour nodes (the full shading; register heavy), so that the
 // illumination nodes do not run at the colour path's two waves per SIMD.
 template <bool ILLUM>
-__global__ __launch_bounds__(BLOCK, ILLUM ? 3 : RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
+__global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
                                                   uint32_t level, uint32_t aov) {
     __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
     __shared__ LevelMap map;
