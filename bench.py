@@ -71,13 +71,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # Rehearsal hook for a one-GPU box (tests only): MI355RT_BENCH_REHEARSE=1 puts every rank on cuda:0 and exchanges
+    # over gloo, so the N > 1 control flow of this file can be run where RCCL cannot (one GPU cannot hold two ranks).
+    rehearse = os.environ.get("MI355RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     config_tag = "BASELINE configs[2]"
     if args.scene == "synthetic":

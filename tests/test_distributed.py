@@ -70,3 +70,24 @@ def test_two_rank_gloo_frame_equals_single_rank(libs, tmp_path, sample_shards, u
         assert np.array_equal(frame, full)  # tile shards: one non-zero contributor per pixel
     else:
         assert np.allclose(frame, full, rtol=0, atol=1e-12)  # sample shards: f64 re-association only
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """bench.py's N > 1 control flow (torch.distributed.run, shard plan, frame exchange, counter reduce, the JSON
+    line) with both ranks on cuda:0 exchanging over gloo (MI355RT_BENCH_REHEARSE=1): RCCL itself needs one GPU per
+    rank, which only the driver's multi-GPU node has."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MI355RT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--pool-gib", "6"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["parallelism"] == "tiles2"
+    assert abs(line["config"]["rays_per_step"] - 147120917) <= 200 and line["value"] > 0
+    assert "roofline" not in line and "cpu_baseline" not in line  # rank 0 at N = 1 only
