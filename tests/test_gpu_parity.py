@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_scene
+from conftest import GOLDEN, SCENES, load_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -234,12 +234,57 @@ EDGE_CASES = {
 }
 
 
+_TEX = {"type": "phong", "color": [1, 1, 1], "texture": "textures/checker.png"}
+_PTEX = {"type": "physical", "color": [0.9, 0.8, 0.7], "roughness": 0.4, "metalness": 0.3, "texture": "textures/test.jpg"}
+EDGE_CASES.update({
+    # uv of each primitive kind + nearest-texel lookup (texture.rs:46-69), both materials
+    "textured_all_kinds": _scene_json(width=40, height=30, camera={"position": [0, 2, 7], "target": [0, 0.5, 0]}, objects=[
+        {"type": "plane", "transform": [{"translate": [0, -1, 0]}], "material": _TEX},
+        {"type": "sphere", "transform": [{"translate": [-2, 0, 0]}], "material": _PTEX},
+        {"type": "cube", "size": 1.5, "transform": [{"rotate": [[0, 1, 0], 30]}, {"translate": [0.2, 0, 0]}], "material": _TEX},
+        {"type": "triangle", "vertex_data": [{"position": [1.5, -1, 0], "normal": [0, 0, 1], "texcoords": [0, 0]},
+                                             {"position": [3.5, -1, 0], "normal": [0, 0, 1], "texcoords": [3, 0]},
+                                             {"position": [2.5, 1.5, -1], "normal": [0, 0.5, 1], "texcoords": [1.5, -2]}],
+         "material": dict(_PTEX, side="Both")}]),
+    # groups inside groups, un-normalised rotation axes (quirk Q1), non-uniform scale, a mesh under all of it
+    "nested_sheared_groups": _scene_json(width=36, height=36, camera={"position": [0, 3, 9], "target": [0, 0, 0], "fov": 50}, objects=[
+        {"type": "group", "transform": [{"rotate": [[1, 0, -1], -30]}, {"translate": [0, 0.5, 0]}], "children": [
+            {"type": "group", "transform": [{"scale": [1.5, 0.5, 1]}, {"rotate": [[-0.25, 0.9, 0], 40]}], "children": [
+                {"type": "cube", "size": 2, "material": {"type": "phong", "color": [0.2, 0.6, 1], "reflectivity": 0.3}},
+                {"type": "sphere", "radius": 0.7, "transform": [{"translate": [0, 2, 0]}],
+                 "material": {"type": "physical", "color": [1, 0.3, 0.3], "roughness": 0.1, "metalness": 1}}]},
+            {"type": "mesh", "file": "models/cornell_box/short_block.obj", "transform": [{"scale": [0.01, 0.01, 0.01]}, {"translate": [-3, -1, 0]}],
+             "material": {"type": "phong", "color": [0.8, 0.8, 0.2]}}]},
+        {"type": "plane", "transform": [{"translate": [0, -2, 0]}], "material": {"type": "phong", "color": [0.5, 0.5, 0.5]}}]),
+    # Cornell-box scale (coordinates ~550, BIAS 1e-10 far below f32 resolution) with a tiny emissive sphere
+    "huge_and_tiny": _scene_json(width=32, height=32, max_occlusion_distance=100.0,
+                                 camera={"position": [278, 273, -800], "target": [278, 273, 0], "fov": 38.2},
+                                 lights=[{"type": "point", "transform": [{"translate": [278, 540, 279]}], "intensity": 100000}],
+                                 objects=[{"type": "mesh", "file": "models/cornell_box/floor.obj", "material": {"type": "phong", "color": [0.7, 0.7, 0.7]}},
+                                          {"type": "mesh", "file": "models/cornell_box/back_wall.obj", "material": {"type": "phong", "color": [0.7, 0.2, 0.2]}},
+                                          {"type": "sphere", "radius": 0.001, "transform": [{"scale": [50000, 50000, 50000]}, {"translate": [278, 100, 279]}],
+                                           "material": {"type": "physical", "color": [1, 1, 1], "emissive": [0.5, 0.5, 0.1], "roughness": 0.9}}]),
+    # one reflected ray, one GI ray, two refractive shells inside each other (ior carried by the ray, quirk Q11 / Q20)
+    "single_ray_budgets_nested_glass": _scene_json(width=30, height=30, max_depth=5, max_reflected_rays=1, max_illumination_rays=1, objects=[
+        {"type": "sphere", "radius": 1.5, "material": {"type": "physical", "color": [1, 1, 1], "opacity": 0.1, "refractive_index": 1.5, "roughness": 0.0}},
+        {"type": "sphere", "radius": 0.7, "material": {"type": "physical", "side": "Both", "color": [0.2, 1, 0.4], "opacity": 0.5, "refractive_index": 1.1}},
+        {"type": "plane", "normal": [0, 0, 1], "transform": [{"translate": [0, 0, -4]}], "material": dict(_TEX, emissive=[0.1, 0.1, 0.1])}]),
+    # light inside a Back-sided cube (inner faces shaded), ambient only outside contribution; no point light reaches the outer sphere
+    "light_inside_back_cube": _scene_json(width=28, height=20, camera={"position": [0, 0, 0.5], "target": [0, 0, -1], "fov": 100},
+                                          lights=[{"type": "ambient", "color": [0.05, 0.05, 0.05]}, {"type": "point", "transform": [{"translate": [0, 1, 0]}], "intensity": 3}],
+                                          objects=[{"type": "cube", "size": 6, "material": {"type": "phong", "side": "Back", "color": [0.6, 0.6, 0.9], "specular": [1, 1, 1], "shininess": 8}},
+                                                   {"type": "sphere", "radius": 0.5, "transform": [{"translate": [1, -1, -2]}],
+                                                    "material": {"type": "phong", "color": [1, 0.4, 0.1], "reflectivity": 1.0}},
+                                                   {"type": "sphere", "radius": 2, "transform": [{"translate": [0, 0, -12]}], "material": {"type": "phong", "color": [1, 1, 1]}}]),
+})
+
+
 @pytest.mark.parametrize("case", sorted(EDGE_CASES))
 def test_edge_cases(rt, case):
     device, ob, _ = rt
     from raytracer_amd import host
 
-    s = host.LoadedScene.from_string(EDGE_CASES[case])
+    s = host.LoadedScene.from_string(EDGE_CASES[case], asset_base=SCENES)
     gpu, cpu = device.DeviceScene(s.desc), ob.OracleScene(s.desc)
     check_primary(gpu, cpu, ob)
     acc_g, rgba_g, n_g, _ = gpu.render()
