@@ -198,7 +198,7 @@ int ensure_pools(rt_scene *s) {
         s->pool_mem = nullptr;
     }
     // bytes per node: ray 64 + hit 28 + info 16; per shadow ray: 34; shadow capacity = nodes / 2
-    const uint64_t per_node = 108, per_shadow = 34;
+    const uint64_t per_node = 112, per_shadow = 34;
     uint64_t cap = s->pool_bytes / (per_node + per_shadow / 2 + 8);
     cap = std::min<uint64_t>(cap, 1ull << 31);
     cap &= ~uint64_t(255);
@@ -224,6 +224,7 @@ int ensure_pools(rt_scene *s) {
     np.meta = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.prim = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.xinfo = reinterpret_cast<ExpandInfo *>(take(cap * 16));
+    np.live = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.capacity = static_cast<uint32_t>(cap);
     ShadowPool &sp = s->sp;
     sp.s0 = reinterpret_cast<Vec2d *>(take(scap * 16));
@@ -553,7 +554,7 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     {   // top of the tree kept in LDS by the traversal kernels: as many nodes as fit next to the per-lane stacks
         // without costing a block per CU (four 256-thread blocks share 160 KB), at most 512 (16 KB)
         const uint32_t stack_bytes = (bvh.max_depth + 2u) * BLOCK * static_cast<uint32_t>(sizeof(uint32_t));
-        const uint32_t budget = 40u * 1024u - 1024u;  // per block; 1 KB for the kernels' static LDS
+        const uint32_t budget = 40u * 1024u - 2048u;  // per block; 2 KB for the kernels' static LDS (work map, live-list masks)
         const uint32_t fit = stack_bytes < budget ? (budget - stack_bytes) / static_cast<uint32_t>(sizeof(BvhNode)) : 0u;
         dev.n_top_nodes = static_cast<uint32_t>(std::min<size_t>(bvh.nodes.size(), std::min(fit, 512u)));
     }
@@ -728,6 +729,7 @@ int rt_render_aov_device(rt_scene *s, const rt_render_params *params, double *d_
                 else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level, stack_entries(s));
                 timer.end();
                 timer.begin(CLS_EXPAND);
+                hipLaunchKernelGGL(k_build_live, dim3(level == 0 ? shard_grid(s, sh, n / 4 + 1, 8) : g_wide), dim3(BLOCK), 0, stream, np, s->d_ctr, sh, level);
                 const uint32_t ge = level == 0 ? shard_grid(s, sh, n, 8) : g_wide;
                 if (count_work) hipLaunchKernelGGL(k_expand<true>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, s->d_ctr, sh, level);
                 else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, s->d_ctr, sh, level);

@@ -161,6 +161,10 @@ struct NodePool {
     uint32_t *prim;
     double *t, *bu, *bv;
     ExpandInfo *xinfo;  // written by k_expand for the nodes it expands, read by k_resolve
+    // Live lists: the nodes of a level that still need k_expand / k_resolve (not finished by the trace kernel), written
+    // by the trace kernel into the level's own index range of this array -- colour nodes from the range's start
+    // upwards, illumination nodes from its end downwards (Counters::live_colour / live_illum count them).
+    uint32_t *live;
     uint32_t capacity;
 };
 
@@ -177,6 +181,7 @@ struct Counters {
     uint32_t level_count[MAX_LEVELS + 1];
     unsigned long long node_alloc;    // bump pointer into the node pool
     unsigned long long shadow_alloc;  // bump pointer into the shadow pool
+    uint32_t live_colour[MAX_LEVELS + 1], live_illum[MAX_LEVELS + 1];  // entries of NodePool::live per level
     uint32_t overflow;       // a pool ran out: the batch must be re-run smaller
     uint32_t active_camera;  // camera rays inside the window
     unsigned long long nodes_visited_closest, prims_tested_closest;

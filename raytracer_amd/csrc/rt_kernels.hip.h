@@ -116,14 +116,71 @@ __device__ __forceinline__ uint32_t level_map_build(LevelMap &m, const Counters 
     return m.dead ? 0u : m.prefix[sh.count];
 }
 // group -> (pool index of its first entry, valid entries in it)
-__device__ __forceinline__ uint32_t level_map_group(const LevelMap &m, const Shards &sh, uint32_t group, uint32_t *n_valid) {
+__device__ __forceinline__ uint32_t level_map_group(const LevelMap &m, const Shards &sh, uint32_t group, uint32_t *n_valid,
+                                                   uint32_t *shard = nullptr) {
     uint32_t k = 0;
 #pragma unroll
     for (uint32_t step = MAX_SHARDS / 2; step >= 1; step >>= 1)
         if (k + step < sh.count && m.prefix[k + step] <= group) k += step;
     const uint32_t first = (group - m.prefix[k]) * 64u;
     *n_valid = min(64u, m.count[k] - first);
+    if (shard) *shard = k;
     return m.base[k] + first;
+}
+
+// Work map over the LIVE nodes of a level (NodePool::live, written by k_build_live): per shard the colour list and /
+// or the illumination list, again as one list of 64-entry groups.  Built like LevelMap; a group resolves to 64
+// consecutive list entries.
+struct LiveMap {
+    uint32_t prefix[MAX_SHARDS + 1];  // groups before shard k
+    uint32_t lo[MAX_SHARDS], hi[MAX_SHARDS];  // the level's index range of shard k in NodePool::live: [lo, hi)
+    uint32_t n_colour[MAX_SHARDS], n_illum[MAX_SHARDS];
+    uint32_t dead;
+};
+__device__ __forceinline__ uint32_t live_map_build(LiveMap &m, const Counters *ctrs, const Shards &sh, uint32_t level, bool colour,
+                                                  bool illum) {
+    if (threadIdx.x < 64u) {
+        const uint32_t k = threadIdx.x;
+        uint32_t nc = 0, ni = 0, over = 0;
+        if (k < sh.count) {
+            nc = colour ? ctrs[k].live_colour[level] : 0u;
+            ni = illum ? ctrs[k].live_illum[level] : 0u;
+            over = ctrs[k].overflow;
+            m.lo[k] = k * sh.node_cap + ctrs[k].level_start[level];
+            m.hi[k] = m.lo[k] + ctrs[k].level_count[level];
+            m.n_colour[k] = nc;
+            m.n_illum[k] = ni;
+        }
+        uint32_t x = (nc + 63u) / 64u + (ni + 63u) / 64u;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            if (k >= off) x += y;
+        }
+        if (k < sh.count) m.prefix[k + 1] = x;
+        if (k == 0) m.prefix[0] = 0;
+        const unsigned long long any_over = __ballot(over != 0);
+        if (k == 0) m.dead = any_over ? 1u : 0u;
+    }
+    __syncthreads();
+    return m.dead ? 0u : m.prefix[sh.count];
+}
+// group, lane -> node index (0xFFFFFFFF when the lane has no entry)
+__device__ __forceinline__ uint32_t live_map_node(const LiveMap &m, const Shards &sh, const uint32_t *__restrict__ live, uint32_t group,
+                                                 uint32_t lane) {
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t step = MAX_SHARDS / 2; step >= 1; step >>= 1)
+        if (k + step < sh.count && m.prefix[k + step] <= group) k += step;
+    uint32_t g = group - m.prefix[k];
+    const uint32_t gc = (m.n_colour[k] + 63u) / 64u;
+    if (g < gc) {  // colour entries grow upwards from lo
+        const uint32_t e = g * 64u + lane;
+        return e < m.n_colour[k] ? live[m.lo[k] + e] : 0xFFFFFFFFu;
+    }
+    g -= gc;       // illumination entries grow downwards from hi
+    const uint32_t e = g * 64u + lane;
+    return e < m.n_illum[k] ? live[m.hi[k] - 1u - e] : 0xFFFFFFFFu;
 }
 
 // Wave-aggregated bump allocation: every lane of the wave must call it.
@@ -261,6 +318,7 @@ __global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
         ctr->level_start[i] = 0;
         ctr->level_count[i] = 0;
     }
+    for (uint32_t i = 0; i <= MAX_LEVELS; ++i) ctr->live_colour[i] = ctr->live_illum[i] = 0;
     ctr->level_count[0] = local;  // items past n_items are padding (META_INACTIVE)
     ctr->node_alloc = local;
     ctr->shadow_alloc = 0;
@@ -283,6 +341,63 @@ __global__ void k_advance_level(Counters *ctrs, Shards sh, uint32_t level) {
     if (ctr->node_alloc > sh.node_cap || ctr->shadow_alloc > sh.shadow_cap) ctr->overflow = 1;
     ctr->level_start[level + 1] = start;
     ctr->level_count[level + 1] = ctr->overflow ? 0u : static_cast<uint32_t>(ctr->node_alloc) - start;
+}
+
+// Live lists of a level, after its closest-hit launch: the nodes k_expand / k_resolve still have to visit (not
+// finished by the trace kernel, not padding; 1 in 5) go to the level's own index range of NodePool::live -- colour
+// nodes from its start upwards, illumination nodes from its end downwards.  Those kernels then read full groups of 64
+// live nodes; before, each of them scanned the meta words of every node of the level (three scans of 108 M words a
+// frame, wave-serial).  A wave takes four consecutive groups at a time and bumps the counters once per shard and kind
+// (a returning atomic is microseconds; the scan itself is one coalesced load per group).
+constexpr uint32_t LIVE_GROUPS = 4;
+__global__ __launch_bounds__(BLOCK) void k_build_live(NodePool np, Counters *ctrs, Shards shards, uint32_t level) {
+    __shared__ LevelMap map;
+    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t g0 = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * LIVE_GROUPS; g0 < n_groups;
+         g0 += gridDim.x * (BLOCK / 64) * LIVE_GROUPS) {
+        uint32_t node[LIVE_GROUPS], shard[LIVE_GROUPS];
+        unsigned long long m_c[LIVE_GROUPS], m_i[LIVE_GROUPS];
+#pragma unroll
+        for (uint32_t j = 0; j < LIVE_GROUPS; ++j) {
+            uint32_t n_valid = 0;
+            shard[j] = 0;
+            node[j] = g0 + j < n_groups ? level_map_group(map, shards, g0 + j, &n_valid, &shard[j]) + lane : 0u;
+            const uint32_t meta = lane < n_valid ? np.meta[node[j]] : META_INACTIVE;
+            const bool live = !(meta & (META_INACTIVE | META_DONE));
+            m_c[j] = __ballot(live && !(meta & META_ILLUM));
+            m_i[j] = __ballot(live && (meta & META_ILLUM));
+        }
+        for (uint32_t j0 = 0; j0 < LIVE_GROUPS;) {  // runs of groups in the same shard (almost always one run)
+            uint32_t j1 = j0, tot_c = 0, tot_i = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < LIVE_GROUPS; ++j)
+                if (j >= j0 && j1 == j && shard[j] == shard[j0]) {
+                    tot_c += static_cast<uint32_t>(__popcll(m_c[j]));
+                    tot_i += static_cast<uint32_t>(__popcll(m_i[j]));
+                    j1 = j + 1;
+                }
+            const uint32_t k = shard[j0];
+            uint32_t b_c = 0, b_i = 0;
+            if (lane == 0) {
+                if (tot_c) b_c = atomicAdd(&ctrs[k].live_colour[level], tot_c);
+                if (tot_i) b_i = atomicAdd(&ctrs[k].live_illum[level], tot_i);
+            }
+            b_c = __shfl(b_c, 0, 64);
+            b_i = __shfl(b_i, 0, 64);
+            const uint32_t lo = map.base[k], hi = lo + map.count[k];
+#pragma unroll
+            for (uint32_t j = 0; j < LIVE_GROUPS; ++j)
+                if (j >= j0 && j < j1) {
+                    if ((m_c[j] >> lane) & 1ull) np.live[lo + b_c + static_cast<uint32_t>(__popcll(m_c[j] & below))] = node[j];
+                    if ((m_i[j] >> lane) & 1ull) np.live[hi - 1u - (b_i + static_cast<uint32_t>(__popcll(m_i[j] & below)))] = node[j];
+                    b_c += static_cast<uint32_t>(__popcll(m_c[j]));
+                    b_i += static_cast<uint32_t>(__popcll(m_i[j]));
+                }
+            j0 = j1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ ray generation
@@ -688,47 +803,9 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
 //      consecutive records (phase A's per-parent loops wrote 64 strided ones and
 //      left lanes of missed rays idle).  Same for the shadow rays.
 // Child order (parent-major, slot-minor) and RNG keys are unchanged.
-// Wave-level compaction of the nodes that still need work (not META_DONE, not
-// padding): each wave scans 64 nodes at a time, appends the live ones to its own
-// queue in LDS and runs the heavy path only on full groups of 64 (and once on the
-// tail), so the heavy path always has (nearly) all lanes busy.  Purely
-// wave-local: no block barrier.
-struct WaveQueue {
-    uint32_t *q;   // 128 entries of this wave
-    uint32_t n;    // wave-uniform fill
-    uint32_t base; // next 64-node group of the level's work map this wave scans
-};
-__device__ __forceinline__ void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
-
-// Scans until 64 live nodes are queued or the wave's share of the level's groups
-// is exhausted; returns how many to process now (0 = finished).  A node is live
-// when (meta & live_mask) == live_value.
-__device__ __forceinline__ uint32_t queue_fill(WaveQueue &wq, const uint32_t *__restrict__ meta, const LevelMap &map,
-                                              const Shards &shards, uint32_t n_groups, uint32_t stride, uint32_t lane,
-                                              uint32_t live_mask = META_INACTIVE | META_DONE, uint32_t live_value = 0u) {
-    while (wq.n < 64u && wq.base < n_groups) {
-        uint32_t n_valid;
-        const uint32_t idx = level_map_group(map, shards, wq.base, &n_valid) + lane;
-        const bool live = lane < n_valid && (meta[idx] & live_mask) == live_value;
-        const unsigned long long mask = __ballot(live);
-        if (live) wq.q[wq.n + __popcll(mask & ((1ull << lane) - 1ull))] = idx;
-        wq.n += static_cast<uint32_t>(__popcll(mask));
-        wq.base += stride;
-    }
-    wave_sync_lds();
-    return wq.n < 64u ? wq.n : 64u;
-}
-// Drops the first `n_proc` entries.
-__device__ __forceinline__ void queue_pop(WaveQueue &wq, uint32_t n_proc, uint32_t lane) {
-    const uint32_t rest = wq.n - n_proc;
-    uint32_t tmp = 0;
-    if (lane < rest) tmp = wq.q[n_proc + lane];
-    wave_sync_lds();
-    if (lane < rest) wq.q[lane] = tmp;
-    wave_sync_lds();
-    wq.n = rest;
-}
-
+// The nodes that still need work (not finished by the trace kernel, not padding) come from the level's live lists
+// (NodePool::live, LiveMap, k_build_live): every wave takes groups of 64 live nodes, so the heavy path has (nearly)
+// all lanes busy.
 struct ExpandLds {
     double Px[BLOCK], Py[BLOCK], Pz[BLOCK];     // hit point
     double nx[BLOCK], ny[BLOCK], nz[BLOCK];     // shading normal
@@ -756,22 +833,18 @@ template <bool COUNT>
 __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, Counters *ctrs,
                                                  Shards shards, uint32_t level) {
     __shared__ ExpandLds L;
-    __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
-    __shared__ LevelMap map;
+    __shared__ LiveMap map;
     const ShardCtx c = shard_ctx(ctrs, shards);  // the shard this block ALLOCATES children and shadow rays from
     Counters *ctr = c.ctr;
-    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
+    const uint32_t n_groups = live_map_build(map, ctrs, shards, level, true, true);
     const bool next_real = level + 1 < sc.opts.max_depth;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
     const uint32_t child_depth = level + 1;
-    WaveQueue wq;
-    wq.q = queue_lds + (tid >> 6) * 128u;
-    wq.n = 0;
-    wq.base = blockIdx.x * (BLOCK / 64) + (tid >> 6);
     const uint32_t wave_stride = gridDim.x * (BLOCK / 64);
-    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, map, shards, n_groups, wave_stride, lane)) != 0; queue_pop(wq, n_proc, lane)) {
-        const bool valid = lane < n_proc;
-        const uint32_t idx = valid ? wq.q[lane] : 0u;
+    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (tid >> 6); g < n_groups; g += wave_stride) {
+        const uint32_t node = live_map_node(map, shards, np.live, g, lane);
+        const bool valid = node != 0xFFFFFFFFu;
+        const uint32_t idx = valid ? node : 0u;
         uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0, phong_flag = 0;
         uint32_t prim = RT_NO_HIT, meta = 0;
         if (valid) {
@@ -958,21 +1031,14 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
 template <bool ILLUM>
 __global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
                                                   uint32_t level, uint32_t aov) {
-    __shared__ uint32_t queue_lds[(BLOCK / 64) * 128];
-    __shared__ LevelMap map;
-    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
+    __shared__ LiveMap map;
+    const uint32_t n_groups = live_map_build(map, ctrs, shards, level, !ILLUM, ILLUM);
     const bool next_real = level + 1 < sc.opts.max_depth;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    WaveQueue wq;
-    wq.q = queue_lds + (tid >> 6) * 128u;
-    wq.n = 0;
-    wq.base = blockIdx.x * (BLOCK / 64) + (tid >> 6);
     const uint32_t wave_stride = gridDim.x * (BLOCK / 64);
-    for (uint32_t n_proc; (n_proc = queue_fill(wq, np.meta, map, shards, n_groups, wave_stride, lane, META_INACTIVE | META_DONE | META_ILLUM,
-                                               ILLUM ? META_ILLUM : 0u)) != 0;
-         queue_pop(wq, n_proc, lane)) {
-        if (lane >= n_proc) continue;
-        const uint32_t idx = wq.q[lane];
+    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (tid >> 6); g < n_groups; g += wave_stride) {
+        const uint32_t idx = live_map_node(map, shards, np.live, g, lane);
+        if (idx == 0xFFFFFFFFu) continue;
         const uint32_t meta = np.meta[idx];
         const uint32_t prim = np.prim[idx];
         d3 result = mk3(0.0, 0.0, 0.0);
