@@ -350,53 +350,55 @@ __global__ void k_advance_level(Counters *ctrs, Shards sh, uint32_t level) {
 // frame, wave-serial).  A wave takes four consecutive groups at a time and bumps the counters once per shard and kind
 // (a returning atomic is microseconds; the scan itself is one coalesced load per group).
 constexpr uint32_t LIVE_GROUPS = 4;
+// N consecutive groups of shard k, `n_entries` nodes from pool index `first_node` on: one atomic per kind for all of them.
+template <uint32_t N>
+__device__ __forceinline__ void live_scan(const NodePool &np, Counters *ctrs, uint32_t level, uint32_t k, uint32_t lo, uint32_t hi,
+                                          uint32_t first_node, uint32_t n_entries, uint32_t lane) {
+    unsigned long long m_c[N], m_i[N];
+    uint32_t tot_c = 0, tot_i = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+        const uint32_t meta = j * 64u + lane < n_entries ? np.meta[first_node + j * 64u + lane] : META_INACTIVE;
+        const bool live = !(meta & (META_INACTIVE | META_DONE));
+        m_c[j] = __ballot(live && !(meta & META_ILLUM));
+        m_i[j] = __ballot(live && (meta & META_ILLUM));
+        tot_c += static_cast<uint32_t>(__popcll(m_c[j]));
+        tot_i += static_cast<uint32_t>(__popcll(m_i[j]));
+    }
+    uint32_t b_c = 0, b_i = 0;
+    if (lane == 0) {
+        if (tot_c) b_c = atomicAdd(&ctrs[k].live_colour[level], tot_c);
+        if (tot_i) b_i = atomicAdd(&ctrs[k].live_illum[level], tot_i);
+    }
+    b_c = __builtin_amdgcn_readfirstlane(b_c);
+    b_i = __builtin_amdgcn_readfirstlane(b_i);
+#pragma unroll
+    for (uint32_t j = 0; j < N; ++j) {
+        const uint32_t node = first_node + j * 64u + lane;
+        const uint32_t r_c = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_c[j] >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_c[j]), 0u));
+        const uint32_t r_i = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m_i[j] >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m_i[j]), 0u));
+        if ((m_c[j] >> lane) & 1ull) np.live[lo + b_c + r_c] = node;
+        if ((m_i[j] >> lane) & 1ull) np.live[hi - 1u - (b_i + r_i)] = node;
+        b_c += static_cast<uint32_t>(__popcll(m_c[j]));
+        b_i += static_cast<uint32_t>(__popcll(m_i[j]));
+    }
+}
 __global__ __launch_bounds__(BLOCK) void k_build_live(NodePool np, Counters *ctrs, Shards shards, uint32_t level) {
     __shared__ LevelMap map;
-    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t g0 = (blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * LIVE_GROUPS; g0 < n_groups;
-         g0 += gridDim.x * (BLOCK / 64) * LIVE_GROUPS) {
-        uint32_t node[LIVE_GROUPS], shard[LIVE_GROUPS];
-        unsigned long long m_c[LIVE_GROUPS], m_i[LIVE_GROUPS];
-#pragma unroll
-        for (uint32_t j = 0; j < LIVE_GROUPS; ++j) {
-            uint32_t n_valid = 0;
-            shard[j] = 0;
-            node[j] = g0 + j < n_groups ? level_map_group(map, shards, g0 + j, &n_valid, &shard[j]) + lane : 0u;
-            const uint32_t meta = lane < n_valid ? np.meta[node[j]] : META_INACTIVE;
-            const bool live = !(meta & (META_INACTIVE | META_DONE));
-            m_c[j] = __ballot(live && !(meta & META_ILLUM));
-            m_i[j] = __ballot(live && (meta & META_ILLUM));
-        }
-        for (uint32_t j0 = 0; j0 < LIVE_GROUPS;) {  // runs of groups in the same shard (almost always one run)
-            uint32_t j1 = j0, tot_c = 0, tot_i = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < LIVE_GROUPS; ++j)
-                if (j >= j0 && j1 == j && shard[j] == shard[j0]) {
-                    tot_c += static_cast<uint32_t>(__popcll(m_c[j]));
-                    tot_i += static_cast<uint32_t>(__popcll(m_i[j]));
-                    j1 = j + 1;
-                }
-            const uint32_t k = shard[j0];
-            uint32_t b_c = 0, b_i = 0;
-            if (lane == 0) {
-                if (tot_c) b_c = atomicAdd(&ctrs[k].live_colour[level], tot_c);
-                if (tot_i) b_i = atomicAdd(&ctrs[k].live_illum[level], tot_i);
-            }
-            b_c = __shfl(b_c, 0, 64);
-            b_i = __shfl(b_i, 0, 64);
-            const uint32_t lo = map.base[k], hi = lo + map.count[k];
-#pragma unroll
-            for (uint32_t j = 0; j < LIVE_GROUPS; ++j)
-                if (j >= j0 && j < j1) {
-                    if ((m_c[j] >> lane) & 1ull) np.live[lo + b_c + static_cast<uint32_t>(__popcll(m_c[j] & below))] = node[j];
-                    if ((m_i[j] >> lane) & 1ull) np.live[hi - 1u - (b_i + static_cast<uint32_t>(__popcll(m_i[j] & below)))] = node[j];
-                    b_c += static_cast<uint32_t>(__popcll(m_c[j]));
-                    b_i += static_cast<uint32_t>(__popcll(m_i[j]));
-                }
-            j0 = j1;
-        }
+    if (level_map_build(map, ctrs, shards, level, false) == 0) return;
+    // Chunks of LIVE_GROUPS groups are dealt shard by shard (chunk c: shard c % K, the shard's c / K-th chunk), so the
+    // waves running at any moment bump the counters of all shards, not the one or two whose groups are next in the
+    // level's list: a counter word takes ~90 returning atomics a microsecond.
+    const uint32_t K = shards.count, per_chunk = 64u * LIVE_GROUPS;
+    uint32_t max_chunks = 0;
+    for (uint32_t k = 0; k < K; ++k) max_chunks = max(max_chunks, (map.count[k] + per_chunk - 1u) / per_chunk);
+    const uint32_t lane = threadIdx.x & 63u, total = max_chunks * K;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+    for (uint32_t c = wave; c < total; c += gridDim.x * (BLOCK / 64)) {
+        const uint32_t k = c % K, first = (c / K) * per_chunk, count = map.count[k];
+        if (first >= count) continue;
+        const uint32_t lo = map.base[k];
+        live_scan<LIVE_GROUPS>(np, ctrs, level, k, lo, lo + count, lo + first, count - first, lane);
     }
 }
 
