@@ -3,12 +3,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_bvh.h"
@@ -93,17 +95,91 @@ bool plane_uv_rotation(const double n[3], double rows[6]) {
     return true;
 }
 
+// Host -> device copy of a scene array.  Large arrays (the 1M-triangle scene uploads 380 MB) go through two pinned
+// 16 MB staging buffers, the CPU filling one while the DMA engine drains the other: a hipMemcpy straight from pageable
+// memory ran at 2 GB/s.
+struct Stager {
+    static constexpr size_t CHUNK = 16u << 20;
+    void *pinned[2] = {nullptr, nullptr};
+    hipEvent_t drained[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    double ms_alloc = 0.0, ms_fill = 0.0, ms_wait = 0.0;  // MI355RT_TIMING: hipMalloc, CPU copies into the staging buffers, waiting for the DMA engine
+    static double since(std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    ~Stager() {
+        for (int i = 0; i < 2; ++i) {
+            if (drained[i]) hipEventDestroy(drained[i]);
+            if (pinned[i]) hipHostFree(pinned[i]);
+        }
+        if (stream) hipStreamDestroy(stream);
+    }
+    int copy(void *dst, const void *src, size_t bytes) {
+        if (bytes < CHUNK) {
+            HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+            return RT_OK;
+        }
+        if (!stream) {
+            HIP_TRY(hipStreamCreate(&stream));
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipHostMalloc(&pinned[i], CHUNK));
+                HIP_TRY(hipEventCreateWithFlags(&drained[i], hipEventDisableTiming));
+            }
+        }
+        int i = 0;
+        for (size_t off = 0; off < bytes; off += CHUNK, i ^= 1) {
+            const size_t n = std::min(CHUNK, bytes - off);
+            auto t0 = std::chrono::steady_clock::now();
+            HIP_TRY(hipEventSynchronize(drained[i]));  // a fresh event is complete
+            ms_wait += since(t0);
+            t0 = std::chrono::steady_clock::now();
+            std::memcpy(pinned[i], static_cast<const char *>(src) + off, n);
+            ms_fill += since(t0);
+            HIP_TRY(hipMemcpyAsync(static_cast<char *>(dst) + off, pinned[i], n, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipEventRecord(drained[i], stream));
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        HIP_TRY(hipStreamSynchronize(stream));
+        ms_wait += since(t0);
+        return RT_OK;
+    }
+};
+
 template <typename T>
-int upload(const std::vector<T> &host, const T **dev, std::vector<void *> &allocs, uint64_t *bytes) {
+int upload(Stager &st, const T *host, size_t count, const T **dev, std::vector<void *> &allocs, uint64_t *bytes) {
     *dev = nullptr;
-    if (host.empty()) return RT_OK;
+    if (count == 0) return RT_OK;
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, host.size() * sizeof(T)));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipMalloc(&p, count * sizeof(T)));
+    st.ms_alloc += Stager::since(t0);
     allocs.push_back(p);
-    HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (int rc = st.copy(p, host, count * sizeof(T))) return rc;
     *dev = static_cast<const T *>(p);
-    *bytes += host.size() * sizeof(T);
+    *bytes += count * sizeof(T);
     return RT_OK;
+}
+template <typename T>
+int upload(Stager &st, const std::vector<T> &host, const T **dev, std::vector<void *> &allocs, uint64_t *bytes) {
+    return upload(st, host.data(), host.size(), dev, allocs, bytes);
+}
+
+// fn(begin, end) over [0, n) on up to 16 host threads (one for small n)
+template <typename F>
+void parallel_for(size_t n, F fn) {
+    const size_t hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t workers = n < 65536 ? 1 : hw;
+    if (workers == 1) {
+        fn(size_t(0), n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + workers - 1) / workers;
+    for (size_t w = 0; w < workers; ++w) {
+        const size_t b = w * per, e = std::min(n, b + per);
+        if (b < e) pool.emplace_back([=, &fn] { fn(b, e); });
+    }
+    for (auto &t : pool) t.join();
 }
 
 uint32_t morton2(uint32_t x, uint32_t y) {
@@ -422,103 +498,127 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     HIP_TRY(hipGetDeviceProperties(&prop, sc->device));
     sc->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-    // ---- flatten primitives
+    // MI355RT_TIMING=1: phase times of this call on stderr (the reference prints its "pre-process scene" time, main.rs:48-56)
+    const bool timing = std::getenv("MI355RT_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "rt_scene_create: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+
+    // ---- flatten primitives: a serial pass checks the description and numbers the bounded primitives, a parallel
+    // one fills the shading records and the boxes
     std::vector<ShadePrim> shade(d->n_prims);
     std::vector<PlanePrim> planes;
-    std::vector<Aabb> boxes;       // reference AABBs (part of the hit predicate)
-    std::vector<Aabb> cull_boxes;  // what the BVH is built from
     std::vector<uint32_t> bounded_ids;
-    std::vector<uint32_t> leaf_group;   // per bounded primitive: which primitives it may share a BVH leaf with
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const uint32_t type = d->prim_type[i];
         if (type > RT_PRIM_TRIANGLE) return fail(RT_ERR_INVALID, "bad primitive type");
         if (d->prim_material[i] >= d->n_materials || d->prim_transform[i] >= d->n_transforms)
             return fail(RT_ERR_INVALID, "primitive references out of range");
         if (d->prim_transform[i] >= (1u << 28)) return fail(RT_ERR_UNSUPPORTED, "too many transforms");
-        ShadePrim &sh = shade[i];
-        std::memset(&sh, 0, sizeof(sh));
-        sh.type = type;
-        sh.material = d->prim_material[i];
-        sh.xf = d->prim_transform[i];
-        sh.tri = 0;
-        sh.param = d->prim_param[i];
-        sh.uv_ok = 1;
-        const rt_material &m = d->materials[sh.material];
-        const uint32_t meta = type | (m.side << 2) | (sh.xf << 4);
-        const double *w = d->world + 12ull * sh.xf;
-        if (type == RT_PRIM_PLANE) {
-            for (int k = 0; k < 3; ++k) sh.normal[k] = d->prim_normal[3ull * i + k];
-            sh.uv_ok = plane_uv_rotation(sh.normal, sh.uv_rot) ? 1u : 0u;
-            PlanePrim pp{};
-            for (int k = 0; k < 3; ++k) pp.normal[k] = sh.normal[k];
-            pp.prim_id = i;
-            pp.meta = meta;
-            planes.push_back(pp);
-            continue;
-        }
-        double mn[3], mx[3];
-        if (type == RT_PRIM_SPHERE) {  // sphere.rs:133-141
-            for (int k = 0; k < 3; ++k) {
-                mn[k] = -sh.param;
-                mx[k] = sh.param;
-            }
-        } else if (type == RT_PRIM_CUBE) {  // cube.rs:177-186
-            double h = sh.param / 2.0;
-            for (int k = 0; k < 3; ++k) {
-                mn[k] = -h;
-                mx[k] = h;
-            }
-        } else {  // triangle.rs:235-251
-            uint32_t t = d->prim_tri[i];
-            if (t >= d->n_tris) return fail(RT_ERR_INVALID, "triangle index out of range");
-            sh.tri = t;
-            const double *p = d->tri_pos + 9ull * t;
-            for (int k = 0; k < 3; ++k) {
-                mn[k] = mx[k] = p[k];
-                for (int v = 1; v < 3; ++v) {
-                    mn[k] = std::fmin(mn[k], p[3 * v + k]);
-                    mx[k] = std::fmax(mx[k], p[3 * v + k]);
-                }
-            }
-        }
-        boxes.push_back(world_aabb(mn, mx, w));
-        // Box the BVH is built from.  A triangle's reference AABB is the transform of its
-        // object-space box (looser than the triangle when the mesh is rotated); every hit
-        // point lies on the triangle itself, so the bounds of the world-space vertices are
-        // a valid -- and tighter -- culling volume.  The exact predicate keeps the loose box.
-        if (type == RT_PRIM_TRIANGLE) {
-            const double *p = d->tri_pos + 9ull * d->prim_tri[i];
-            Aabb tight{};
-            for (int v = 0; v < 3; ++v) {
-                const double x = p[3 * v], y = p[3 * v + 1], z = p[3 * v + 2];
-                const double q[3] = {w[0] * x + w[1] * y + w[2] * z + w[3], w[4] * x + w[5] * y + w[6] * z + w[7],
-                                     w[8] * x + w[9] * y + w[10] * z + w[11]};
-                for (int k = 0; k < 3; ++k) {
-                    tight.mn[k] = v ? std::fmin(tight.mn[k], q[k]) : q[k];
-                    tight.mx[k] = v ? std::fmax(tight.mx[k], q[k]) : q[k];
-                }
-            }
-            bool finite = true;
-            for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(tight.mn[k]) && std::isfinite(tight.mx[k]);
-            // never larger than the reference box (intersection of two valid volumes)
-            for (int k = 0; finite && k < 3; ++k) {
-                tight.mn[k] = std::fmax(tight.mn[k], boxes.back().mn[k]);
-                tight.mx[k] = std::fmin(tight.mx[k], boxes.back().mx[k]);
-                if (tight.mn[k] > tight.mx[k]) finite = false;
-            }
-            cull_boxes.push_back(finite ? tight : boxes.back());
-        } else {
-            cull_boxes.push_back(boxes.back());
-        }
-        bounded_ids.push_back(i);
-        leaf_group.push_back(type == RT_PRIM_TRIANGLE ? sh.xf : NO_LEAF_GROUP);  // a mesh's faces share its transform
+        if (type == RT_PRIM_TRIANGLE && d->prim_tri[i] >= d->n_tris) return fail(RT_ERR_INVALID, "triangle index out of range");
+        if (type != RT_PRIM_PLANE) bounded_ids.push_back(i);
     }
+    parallel_for(d->n_prims, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            ShadePrim &sh = shade[i];
+            std::memset(&sh, 0, sizeof(sh));
+            sh.type = d->prim_type[i];
+            sh.material = d->prim_material[i];
+            sh.xf = d->prim_transform[i];
+            sh.tri = sh.type == RT_PRIM_TRIANGLE ? d->prim_tri[i] : 0u;
+            sh.param = d->prim_param[i];
+            sh.uv_ok = 1;
+            if (sh.type == RT_PRIM_PLANE) {
+                for (int k = 0; k < 3; ++k) sh.normal[k] = d->prim_normal[3ull * i + k];
+                sh.uv_ok = plane_uv_rotation(sh.normal, sh.uv_rot) ? 1u : 0u;
+            }
+        }
+    });
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const ShadePrim &sh = shade[i];
+        if (sh.type != RT_PRIM_PLANE) continue;
+        PlanePrim pp{};
+        for (int k = 0; k < 3; ++k) pp.normal[k] = sh.normal[k];
+        pp.prim_id = i;
+        pp.meta = sh.type | (d->materials[sh.material].side << 2) | (sh.xf << 4);
+        planes.push_back(pp);
+    }
+    const size_t n_bounded = bounded_ids.size();
+    std::vector<Aabb> boxes(n_bounded);       // reference AABBs (part of the hit predicate)
+    std::vector<Aabb> cull_boxes(n_bounded);  // what the BVH is built from
+    std::vector<uint32_t> leaf_group(n_bounded);  // per bounded primitive: which primitives it may share a BVH leaf with
+    parallel_for(n_bounded, [&](size_t b0, size_t b1) {
+        for (size_t b = b0; b < b1; ++b) {
+            const uint32_t i = bounded_ids[b];
+            const ShadePrim &sh = shade[i];
+            const double *w = d->world + 12ull * sh.xf;
+            double mn[3], mx[3];
+            if (sh.type == RT_PRIM_SPHERE) {  // sphere.rs:133-141
+                for (int k = 0; k < 3; ++k) {
+                    mn[k] = -sh.param;
+                    mx[k] = sh.param;
+                }
+            } else if (sh.type == RT_PRIM_CUBE) {  // cube.rs:177-186
+                double h = sh.param / 2.0;
+                for (int k = 0; k < 3; ++k) {
+                    mn[k] = -h;
+                    mx[k] = h;
+                }
+            } else {  // triangle.rs:235-251
+                const double *p = d->tri_pos + 9ull * sh.tri;
+                for (int k = 0; k < 3; ++k) {
+                    mn[k] = mx[k] = p[k];
+                    for (int v = 1; v < 3; ++v) {
+                        mn[k] = std::fmin(mn[k], p[3 * v + k]);
+                        mx[k] = std::fmax(mx[k], p[3 * v + k]);
+                    }
+                }
+            }
+            boxes[b] = world_aabb(mn, mx, w);
+            // Box the BVH is built from.  A triangle's reference AABB is the transform of its
+            // object-space box (looser than the triangle when the mesh is rotated); every hit
+            // point lies on the triangle itself, so the bounds of the world-space vertices are
+            // a valid -- and tighter -- culling volume.  The exact predicate keeps the loose box.
+            cull_boxes[b] = boxes[b];
+            if (sh.type == RT_PRIM_TRIANGLE) {
+                const double *p = d->tri_pos + 9ull * sh.tri;
+                Aabb tight{};
+                for (int v = 0; v < 3; ++v) {
+                    const double x = p[3 * v], y = p[3 * v + 1], z = p[3 * v + 2];
+                    const double q[3] = {w[0] * x + w[1] * y + w[2] * z + w[3], w[4] * x + w[5] * y + w[6] * z + w[7],
+                                         w[8] * x + w[9] * y + w[10] * z + w[11]};
+                    for (int k = 0; k < 3; ++k) {
+                        tight.mn[k] = v ? std::fmin(tight.mn[k], q[k]) : q[k];
+                        tight.mx[k] = v ? std::fmax(tight.mx[k], q[k]) : q[k];
+                    }
+                }
+                bool finite = true;
+                for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(tight.mn[k]) && std::isfinite(tight.mx[k]);
+                // never larger than the reference box (intersection of two valid volumes)
+                for (int k = 0; finite && k < 3; ++k) {
+                    tight.mn[k] = std::fmax(tight.mn[k], boxes[b].mn[k]);
+                    tight.mx[k] = std::fmin(tight.mx[k], boxes[b].mx[k]);
+                    if (tight.mn[k] > tight.mx[k]) finite = false;
+                }
+                if (finite) cull_boxes[b] = tight;
+            }
+            leaf_group[b] = sh.type == RT_PRIM_TRIANGLE ? sh.xf : NO_LEAF_GROUP;  // a mesh's faces share its transform
+        }
+    });
     if (bounded_ids.size() >= (1ull << 28)) return fail(RT_ERR_UNSUPPORTED, "too many bounded primitives");
+
+    lap("flatten primitives, boxes");
 
     // ---- BVH
     BvhBuildResult bvh = build_bvh(cull_boxes, &leaf_group);
+    lap("BVH build");
     std::vector<LeafPrim> leaf(bvh.order.size());
-    for (size_t j = 0; j < bvh.order.size(); ++j) {
+    parallel_for(bvh.order.size(), [&](size_t j0, size_t j1) {
+    for (size_t j = j0; j < j1; ++j) {
         const uint32_t b = bvh.order[j], pid = bounded_ids[b];
         LeafPrim &lp = leaf[j];
         std::memset(&lp, 0, sizeof(lp));
@@ -540,9 +640,11 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         lp.prim_id = pid;
         lp.meta = sh.type | (d->materials[sh.material].side << 2) | (sh.xf << 4);
     }
+    });
     sc->n_nodes = bvh.nodes.size();
     sc->n_leaves = bvh.n_leaves;
     sc->bvh_depth = bvh.max_depth;
+    lap("leaf records");
 
     // ---- upload
     SceneDev &dev = sc->dev;
@@ -572,10 +674,6 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     dev.n_lights = d->n_lights;
     dev.n_point_lights = n_point;
 
-    std::vector<double> inv(d->inv_world, d->inv_world + 12ull * d->n_transforms);
-    std::vector<double> tri_nrm(d->tri_nrm, d->tri_nrm + 9ull * d->n_tris);
-    std::vector<double> tri_uv(d->tri_uv, d->tri_uv + 6ull * d->n_tris);
-    std::vector<rt_material> mats(d->materials, d->materials + d->n_materials);
     std::vector<DLight> lights(d->n_lights);
     for (uint32_t i = 0; i < d->n_lights; ++i) {
         lights[i].kind = d->lights[i].kind;
@@ -598,9 +696,10 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     }
     int rc;
     uint64_t *bytes = &sc->scene_bytes;
-    if ((rc = upload(bvh.nodes, &dev.nodes, sc->allocs, bytes))) return rc;
-    if ((rc = upload(leaf, &dev.leaf_prims, sc->allocs, bytes))) return rc;
-    if ((rc = upload(planes, &dev.planes, sc->allocs, bytes))) return rc;
+    Stager st;
+    if ((rc = upload(st, bvh.nodes, &dev.nodes, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, leaf, &dev.leaf_prims, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, planes, &dev.planes, sc->allocs, bytes))) return rc;
     // get_emissive_phong (:135-167) adds a child only if reflectivity > 0; get_emissive_physical (:263-337)
     // only if max_reflected_rays > 0 or opacity < 1: otherwise an illumination ray's result is the emissive colour
     std::vector<uint32_t> prim_flags(d->n_prims);
@@ -610,15 +709,17 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
         const bool emissive = m.emissive[0] != 0.0 || m.emissive[1] != 0.0 || m.emissive[2] != 0.0;
         prim_flags[i] = (terminal ? PRIM_ILLUM_TERMINAL : 0u) | (emissive ? PRIM_EMISSIVE : 0u);
     }
-    if ((rc = upload(shade, &dev.shade_prims, sc->allocs, bytes))) return rc;
-    if ((rc = upload(prim_flags, &dev.prim_flags, sc->allocs, bytes))) return rc;
-    if ((rc = upload(inv, &dev.inv_world, sc->allocs, bytes))) return rc;
-    if ((rc = upload(tri_nrm, &dev.tri_nrm, sc->allocs, bytes))) return rc;
-    if ((rc = upload(tri_uv, &dev.tri_uv, sc->allocs, bytes))) return rc;
-    if ((rc = upload(mats, &dev.materials, sc->allocs, bytes))) return rc;
-    if ((rc = upload(lights, &dev.lights, sc->allocs, bytes))) return rc;
-    if ((rc = upload(texs, &dev.textures, sc->allocs, bytes))) return rc;
-    if ((rc = upload(texels, &dev.texels, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, shade, &dev.shade_prims, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, prim_flags, &dev.prim_flags, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, d->inv_world, 12ull * d->n_transforms, &dev.inv_world, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, d->tri_nrm, 9ull * d->n_tris, &dev.tri_nrm, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, d->tri_uv, 6ull * d->n_tris, &dev.tri_uv, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, d->materials, static_cast<size_t>(d->n_materials), &dev.materials, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, lights, &dev.lights, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, texs, &dev.textures, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, texels, &dev.texels, sc->allocs, bytes))) return rc;
+    lap("upload");
+    if (timing) std::fprintf(stderr, "rt_scene_create:   of which hipMalloc %.1f ms, staging fill %.1f ms, DMA wait %.1f ms\n", st.ms_alloc, st.ms_fill, st.ms_wait);
     *out = sc.release();
     return RT_OK;
 }
