@@ -68,7 +68,9 @@ class LoadedScene:
 
     @property
     def desc(self):
-        return lib().rth_scene_desc(self._h)
+        p = lib().rth_scene_desc(self._h)
+        p._owner = self  # the description points into this scene's arrays: keep it alive as long as the pointer
+        return p
 
     def set_option(self, key, value):
         _check(lib().rth_scene_set_option(self._h, key.encode(), float(value)))

@@ -108,6 +108,18 @@ def test_defaults_of_an_empty_scene(libs):
     assert np.array_equal(np.array(d.camera.cam_to_world[:]).reshape(3, 3), np.eye(3))
 
 
+def test_a_description_keeps_its_scene_alive(libs):
+    """`LoadedScene.desc` points into the scene's arrays: taking it from a temporary must not leave it dangling."""
+    import gc
+
+    host, _ = libs
+    d = host.LoadedScene.from_file(os.path.join(SCENES, "test.json")).desc
+    gc.collect()
+    junk = [host.LoadedScene.from_file(os.path.join(SCENES, "refraction.json")) for _ in range(4)]  # reuse freed memory, if any
+    assert (d.contents.opts.width, d.contents.opts.height, d.contents.n_prims) == (800, 800, 9)
+    del junk
+
+
 def test_material_defaults_and_parameters(libs):
     """material.rs:148-225."""
     host, _ = libs
