@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <numeric>
 #include <string>
 #include <thread>
 #include <vector>
@@ -254,6 +255,7 @@ struct rt_scene {
     bool plan_valid = false;  // d_tiles holds the tile list of plan_key
     rt_render_params plan_key{};
     WorkList plan_wl{};
+    bool plan_scattered = false;  // plan_wl is in scattered order (a call of several batches)
     double est_nodes_per_item = 0.0, est_shadows_per_item = 0.0;
 
     ~rt_scene() {
@@ -340,6 +342,7 @@ int plan_tiles(const rt_render_options &o, const rt_render_params *prm, std::vec
     std::vector<uint32_t> &tiles = *tiles_out;
     tiles.clear();
     WorkList &wl = *wl_out;
+    wl.row_mul = 1;
     if (p.shard_count <= 1) {
         tiles = {x0, y0};
         wl.tile_w = x1 - x0;
@@ -374,6 +377,43 @@ int plan_tiles(const rt_render_options &o, const rt_render_params *prm, std::vec
     return RT_OK;
 }
 
+// Camera rays of the first batch of a call (later batches are sized from the expansion the earlier ones showed).
+uint64_t first_batch_items(const rt_scene *s, uint64_t total_items, uint32_t ns) {
+    uint64_t batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, s->np.capacity / 64));
+    if (s->est_nodes_per_item > 0.0) {
+        const double fit = std::min(s->np.capacity / s->est_nodes_per_item, s->sp.capacity / std::max(s->est_shadows_per_item, 1e-9));
+        batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, static_cast<uint64_t>(0.7 * fit)));
+    }
+    return batch;
+}
+
+// A call that needs several batches takes its camera rays in list order, and a batch is sized from the largest
+// expansion (nodes per camera ray) any batch has shown: in image order the batches over the costly part of the image
+// set the size for all (sky above a height field: pools a quarter full on average, 333 batches for config 5 instead of
+// 112).  Such a call gets a scattered order -- rows of the window, or the tiles of a shard, visited with a
+// golden-ratio stride -- so that every batch is a sample of the whole window.  A pixel's result does not depend on
+// the order (RNG keyed by pixel and sample); a call that fits one batch keeps image order, which traces ~1 % faster.
+uint32_t scatter_stride(uint32_t n, uint32_t max_n) {
+    if (n < 16 || n > max_n) return 1u;
+    uint32_t m = static_cast<uint32_t>(0.6180339887498949 * n);
+    while (std::gcd(m, n) != 1u) ++m;
+    return m % n;
+}
+void scatter_order(std::vector<uint32_t> *tiles, WorkList *wl) {
+    if (wl->n_tiles == 1) {
+        wl->row_mul = scatter_stride(wl->tile_h, 65535u);  // the kernels multiply in 32 bits
+        return;
+    }
+    const uint32_t n = wl->n_tiles, stride = scatter_stride(n, 0x7FFFFFFFu);
+    std::vector<uint32_t> out(tiles->size());
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t from = static_cast<uint32_t>((static_cast<uint64_t>(j) * stride) % n);
+        out[2 * j] = (*tiles)[2 * from];
+        out[2 * j + 1] = (*tiles)[2 * from + 1];
+    }
+    tiles->swap(out);
+}
+
 int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStream_t stream) {
     // the tile partition of a call depends on its window / shard fields only: a frame loop
     // (same params every frame) plans, sorts and uploads its tile list once
@@ -398,7 +438,8 @@ int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStrea
         plan->wl.seed = p.seed;
         plan->total_items = static_cast<uint64_t>(plan->wl.n_tiles) * plan->wl.tile_w * plan->wl.tile_h * plan->wl.ns;
         if (plan->total_items > 0xFFFFFFFFull) return fail(RT_ERR_INVALID, "more than 2^32 camera rays in one call");
-        return RT_OK;
+        if (s->plan_scattered == (first_batch_items(s, plan->total_items, plan->wl.ns) < plan->total_items)) return RT_OK;
+        // else: the call now needs (or no longer needs) several batches -- plan again in the other order
     }
     s->plan_valid = false;
     std::vector<uint32_t> tiles;
@@ -407,6 +448,8 @@ int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStrea
     if (prc) return prc;
     plan->total_items = static_cast<uint64_t>(wl.n_tiles) * wl.tile_w * wl.tile_h * wl.ns;
     if (plan->total_items > 0xFFFFFFFFull) return fail(RT_ERR_INVALID, "more than 2^32 camera rays in one call");
+    const bool scattered = first_batch_items(s, plan->total_items, wl.ns) < plan->total_items;
+    if (scattered) scatter_order(&tiles, &wl);
     if (wl.n_tiles > s->d_tiles_cap) {
         if (s->d_tiles) hipFree(s->d_tiles);
         s->d_tiles = nullptr;
@@ -420,6 +463,7 @@ int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStrea
     wl.tile_xy = s->d_tiles;
     s->plan_key = key;
     s->plan_wl = wl;
+    s->plan_scattered = scattered;
     s->plan_valid = true;
     return RT_OK;
 }

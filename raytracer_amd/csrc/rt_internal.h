@@ -216,6 +216,7 @@ struct WorkList {
     const uint32_t *tile_xy;  // [n_tiles*2] tile origin (pixels)
     uint32_t n_tiles;
     uint32_t tile_w, tile_h;
+    uint32_t row_mul;         // rows of a tile are visited in the order (r * row_mul) % tile_h (coprime with tile_h; 1 = in order)
     uint32_t x0, y0, x1, y1;  // window clip
     uint32_t s0, ns;          // sample range [s0, s0+ns)
     uint64_t seed;

@@ -48,7 +48,7 @@ __device__ __forceinline__ void item_to_pixel(const WorkList &wl, uint32_t item,
     uint32_t per_tile = wl.tile_w * wl.tile_h;
     uint32_t tile = pl / per_tile, pit = pl % per_tile;
     *px = wl.tile_xy[2 * tile] + pit % wl.tile_w;
-    *py = wl.tile_xy[2 * tile + 1] + pit / wl.tile_w;
+    *py = wl.tile_xy[2 * tile + 1] + ((pit / wl.tile_w) * wl.row_mul) % wl.tile_h;
     *sample = wl.s0 + s_local;
 }
 
