@@ -208,6 +208,7 @@ int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes);
 int rt_render_device(rt_scene *scene, const rt_render_params *params, double *d_rgb_accum,
                      uint64_t *ray_count, rt_render_stats *stats, void *stream);
 
+
 /* As rt_render_device, plus the other two members of the ColorData that screen_raycast returns
  * (src/render/mod.rs:16-20, src/render/raytracing_scene.rs:598-622), which the reference hands to its
  * denoise pass (:645-701):
@@ -233,6 +234,17 @@ int rt_tonemap_device(rt_scene *scene, const double *d_rgb_accum, uint8_t *d_rgb
  * copy back.  rgb_accum (w*h*3 doubles) and rgba8 (w*h*4 bytes) may be NULL. */
 int rt_render(rt_scene *scene, const rt_render_params *params, double *rgb_accum, uint8_t *rgba8,
               uint64_t *ray_count, rt_render_stats *stats);
+
+/* Replaces raytrace_to_buffer's progressively filled window buffer (src/render/raytracing_scene.rs:778-875): the
+ * frame is rendered in `n_passes` passes; pass k completes (all samples) the 8x8 tiles dealt to it in a scattered order
+ * (the reference visits the pixels in a shuffled order, :824-825) and writes `utils::to_argb_u32` (src/utils/mod.rs:14-19)
+ * of their colour into argb[y*width+x] (HOST pointer, w*h words; pixels not rendered yet are 0 as in :800-801).  After
+ * every pass `on_pass(user, passes_done, n_passes, rays_so_far)` is called (may be NULL) with `argb` up to date -- the
+ * place to present the buffer, :865-871; a non-zero return stops the render (the reference stops when its window closes).
+ * After the last pass `argb` holds the same pixels as rt_render's rgba8.  rgb_accum (HOST, w*h*3 doubles) may be NULL. */
+typedef int (*rt_progress_fn)(void *user, uint32_t passes_done, uint32_t n_passes, uint64_t rays_so_far);
+int rt_render_progressive(rt_scene *scene, const rt_render_params *params, uint32_t n_passes, uint32_t *argb,
+                          rt_progress_fn on_pass, void *user, double *rgb_accum, uint64_t *ray_count);
 
 /* Parity AOVs: closest hit of the pixel-centre camera ray of every pixel
  * (get_color's raycast + compute_data, :531-532).  HOST pointers, w*h entries

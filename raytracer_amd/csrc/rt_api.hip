@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <new>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -17,6 +19,7 @@
 #include "rt_bvh.h"
 #include "rt_internal.h"
 #include "rt_kernels.hip.h"
+
 
 namespace {
 
@@ -235,6 +238,24 @@ enum { CLS_RAYGEN = 0, CLS_CLOSEST, CLS_SHADOW, CLS_EXPAND, CLS_RESOLVE, CLS_ACC
 
 }  // namespace
 
+// The wavefront state one render call works in: pools, counters, the tile list of the call's plan.  A scene owns one
+// carved from its hipMalloc'ed pool budget (ensure_pools); rt_render_device_noalloc uses one carved from the library's
+// static device scratch (one per device, fixed size).
+struct RenderCtx {
+    NodePool np{};
+    ShadowPool sp{};
+    Counters *d_ctr = nullptr;
+    Counters *h_ctr = nullptr;  // host copy of the counters (pinned for a scene's own context)
+    uint32_t *d_tiles = nullptr;
+    uint32_t d_tiles_cap = 0;   // tiles
+    bool can_grow = true;       // d_tiles may be re-allocated (false: fixed scratch)
+    bool plan_valid = false;    // d_tiles holds the tile list of plan_key
+    rt_render_params plan_key{};
+    WorkList plan_wl{};
+    bool plan_scattered = false;  // plan_wl is in scattered order (a call of several batches)
+    double est_nodes_per_item = 0.0, est_shadows_per_item = 0.0;
+};
+
 struct rt_scene {
     int device = 0;
     SceneDev dev{};
@@ -246,51 +267,40 @@ struct rt_scene {
     uint64_t pool_bytes = 24ull << 30;  // one batch for 800x800x4spp scene.json (108 M nodes); 8 % of the 288 GB
     void *pool_mem = nullptr;
     uint64_t pool_mem_bytes = 0;
-    NodePool np{};
-    ShadowPool sp{};
-    Counters *d_ctr = nullptr;
-    Counters *h_ctr = nullptr;  // pinned
-    uint32_t *d_tiles = nullptr;
-    uint32_t d_tiles_cap = 0;
-    bool plan_valid = false;  // d_tiles holds the tile list of plan_key
-    rt_render_params plan_key{};
-    WorkList plan_wl{};
-    bool plan_scattered = false;  // plan_wl is in scattered order (a call of several batches)
-    double est_nodes_per_item = 0.0, est_shadows_per_item = 0.0;
+    RenderCtx ctx;
+    void *scratch = nullptr;  // this device's copy of the library's static scratch (hipGetSymbolAddress at create)
 
     ~rt_scene() {
+        int prev = -1;
+        const bool switched = hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
         for (void *p : allocs) hipFree(p);
         if (pool_mem) hipFree(pool_mem);
-        if (d_ctr) hipFree(d_ctr);
-        if (h_ctr) hipHostFree(h_ctr);
-        if (d_tiles) hipFree(d_tiles);
+        if (ctx.d_ctr) hipFree(ctx.d_ctr);
+        if (ctx.h_ctr) hipHostFree(ctx.h_ctr);
+        if (ctx.d_tiles) hipFree(ctx.d_tiles);
+        if (switched) hipSetDevice(prev);
     }
 };
 
 namespace {
 
-int ensure_pools(rt_scene *s) {
-    if (s->pool_mem && s->pool_mem_bytes == s->pool_bytes) return RT_OK;
-    if (s->pool_mem) {
-        hipFree(s->pool_mem);
-        s->pool_mem = nullptr;
-    }
-    // bytes per node: ray 64 + hit 28 + info 16; per shadow ray: 34; shadow capacity = nodes / 2
-    const uint64_t per_node = 112, per_shadow = 34;
-    uint64_t cap = s->pool_bytes / (per_node + per_shadow / 2 + 8);
+// bytes of pool per node: ray 64 + hit 28 + expansion info 16 + live 4 = 112; per shadow ray 34; one shadow ray per two nodes
+constexpr uint64_t POOL_BYTES_PER_NODE = 112 + 34 / 2 + 8;
+
+// Carves the node and shadow pools out of [mem, mem + bytes).  No allocation.
+int carve_pools(void *mem, uint64_t bytes, NodePool *np_out, ShadowPool *sp_out) {
+    uint64_t cap = bytes / POOL_BYTES_PER_NODE;
     cap = std::min<uint64_t>(cap, 1ull << 31);
     cap &= ~uint64_t(255);
     if (cap < 4096) return fail(RT_ERR_NOMEM, "pool budget too small");
     uint64_t scap = (cap / 2) & ~uint64_t(255);
-    HIP_TRY(hipMalloc(&s->pool_mem, s->pool_bytes));
-    s->pool_mem_bytes = s->pool_bytes;
-    char *p = static_cast<char *>(s->pool_mem);
-    auto take = [&](uint64_t bytes) {
+    char *p = static_cast<char *>(mem);
+    auto take = [&](uint64_t n) {
         char *r = p;
-        p += (bytes + 255) & ~uint64_t(255);
+        p += (n + 255) & ~uint64_t(255);
         return r;
     };
-    NodePool &np = s->np;
+    NodePool &np = *np_out;
     np.r0 = reinterpret_cast<Vec2d *>(take(cap * 16));
     np.r1 = reinterpret_cast<Vec2d *>(take(cap * 16));
     np.r2 = reinterpret_cast<Vec2d *>(take(cap * 16));
@@ -304,17 +314,36 @@ int ensure_pools(rt_scene *s) {
     np.xinfo = reinterpret_cast<ExpandInfo *>(take(cap * 16));
     np.live = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.capacity = static_cast<uint32_t>(cap);
-    ShadowPool &sp = s->sp;
+    ShadowPool &sp = *sp_out;
     sp.s0 = reinterpret_cast<Vec2d *>(take(scap * 16));
     sp.s1 = reinterpret_cast<Vec2d *>(take(scap * 16));
     sp.light = reinterpret_cast<uint8_t *>(take(scap));
     sp.occluded = reinterpret_cast<uint8_t *>(take(scap));
     sp.capacity = static_cast<uint32_t>(scap);
-    if (static_cast<uint64_t>(p - static_cast<char *>(s->pool_mem)) > s->pool_bytes)
-        return fail(RT_ERR_NOMEM, "internal: pool carve exceeds budget");
-    if (!s->d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ctr), MAX_SHARDS * sizeof(Counters)));
-    if (!s->h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_ctr), MAX_SHARDS * sizeof(Counters)));
-    s->est_nodes_per_item = s->est_shadows_per_item = 0.0;
+    if (static_cast<uint64_t>(p - static_cast<char *>(mem)) > bytes) return fail(RT_ERR_NOMEM, "internal: pool carve exceeds budget");
+    return RT_OK;
+}
+
+int ensure_pools(rt_scene *s) {
+    RenderCtx &ctx = s->ctx;
+    if (s->pool_mem && s->pool_mem_bytes == s->pool_bytes) return RT_OK;
+    if (s->pool_mem) {
+        hipFree(s->pool_mem);
+        s->pool_mem = nullptr;
+        s->pool_mem_bytes = 0;
+    }
+    // the default budget is a sixth of an idle MI355X; never ask for more than 80 % of what is free right now
+    uint64_t want = s->pool_bytes;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 10 * 8) want = free_b / 10 * 8;
+    if (want < (1ull << 20)) return fail(RT_ERR_NOMEM, "less than 1 MiB of device memory free for the wavefront pools");
+    HIP_TRY(hipMalloc(&s->pool_mem, want));
+    s->pool_mem_bytes = s->pool_bytes;  // the budget this allocation answers (may be clamped)
+    if (int rc = carve_pools(s->pool_mem, want, &ctx.np, &ctx.sp)) return rc;
+    if (!ctx.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx.d_ctr), MAX_SHARDS * sizeof(Counters)));
+    if (!ctx.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx.h_ctr), MAX_SHARDS * sizeof(Counters)));
+    ctx.est_nodes_per_item = ctx.est_shadows_per_item = 0.0;
+    ctx.plan_valid = false;
     return RT_OK;
 }
 
@@ -378,10 +407,10 @@ int plan_tiles(const rt_render_options &o, const rt_render_params *prm, std::vec
 }
 
 // Camera rays of the first batch of a call (later batches are sized from the expansion the earlier ones showed).
-uint64_t first_batch_items(const rt_scene *s, uint64_t total_items, uint32_t ns) {
-    uint64_t batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, s->np.capacity / 64));
-    if (s->est_nodes_per_item > 0.0) {
-        const double fit = std::min(s->np.capacity / s->est_nodes_per_item, s->sp.capacity / std::max(s->est_shadows_per_item, 1e-9));
+uint64_t first_batch_items(const RenderCtx &c, uint64_t total_items, uint32_t ns) {
+    uint64_t batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, c.np.capacity / 64));
+    if (c.est_nodes_per_item > 0.0) {
+        const double fit = std::min(c.np.capacity / c.est_nodes_per_item, c.sp.capacity / std::max(c.est_shadows_per_item, 1e-9));
         batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, static_cast<uint64_t>(0.7 * fit)));
     }
     return batch;
@@ -414,7 +443,7 @@ void scatter_order(std::vector<uint32_t> *tiles, WorkList *wl) {
     tiles->swap(out);
 }
 
-int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStream_t stream) {
+int plan_call(rt_scene *s, RenderCtx &c, const rt_render_params *prm, CallPlan *plan, hipStream_t stream) {
     // the tile partition of a call depends on its window / shard fields only: a frame loop
     // (same params every frame) plans, sorts and uploads its tile list once
     rt_render_params key{};
@@ -422,9 +451,9 @@ int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStrea
     key.seed = 0;
     key.flags = 0;
     key.s0 = key.s1 = 0;
-    if (s->plan_valid && std::memcmp(&key, &s->plan_key, sizeof(key)) == 0) {
+    if (c.plan_valid && std::memcmp(&key, &c.plan_key, sizeof(key)) == 0) {
         *plan = CallPlan{};
-        plan->wl = s->plan_wl;
+        plan->wl = c.plan_wl;
         rt_render_params p{};
         if (prm) p = *prm;
         uint32_t s0 = p.s0, s1 = p.s1;
@@ -438,33 +467,35 @@ int plan_call(rt_scene *s, const rt_render_params *prm, CallPlan *plan, hipStrea
         plan->wl.seed = p.seed;
         plan->total_items = static_cast<uint64_t>(plan->wl.n_tiles) * plan->wl.tile_w * plan->wl.tile_h * plan->wl.ns;
         if (plan->total_items > 0xFFFFFFFFull) return fail(RT_ERR_INVALID, "more than 2^32 camera rays in one call");
-        if (s->plan_scattered == (first_batch_items(s, plan->total_items, plan->wl.ns) < plan->total_items)) return RT_OK;
+        if (c.plan_scattered == (first_batch_items(c, plan->total_items, plan->wl.ns) < plan->total_items)) return RT_OK;
         // else: the call now needs (or no longer needs) several batches -- plan again in the other order
     }
-    s->plan_valid = false;
+    c.plan_valid = false;
     std::vector<uint32_t> tiles;
     WorkList &wl = plan->wl;
     int prc = plan_tiles(s->dev.opts, prm, &tiles, &wl);
     if (prc) return prc;
     plan->total_items = static_cast<uint64_t>(wl.n_tiles) * wl.tile_w * wl.tile_h * wl.ns;
     if (plan->total_items > 0xFFFFFFFFull) return fail(RT_ERR_INVALID, "more than 2^32 camera rays in one call");
-    const bool scattered = first_batch_items(s, plan->total_items, wl.ns) < plan->total_items;
+    const bool scattered = first_batch_items(c, plan->total_items, wl.ns) < plan->total_items;
     if (scattered) scatter_order(&tiles, &wl);
-    if (wl.n_tiles > s->d_tiles_cap) {
-        if (s->d_tiles) hipFree(s->d_tiles);
-        s->d_tiles = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_tiles), tiles.size() * sizeof(uint32_t)));
-        s->d_tiles_cap = wl.n_tiles;
+    if (wl.n_tiles > c.d_tiles_cap) {
+        if (!c.can_grow) return fail(RT_ERR_NOMEM, "tile list of this call exceeds the fixed scratch (" + std::to_string(c.d_tiles_cap) + " tiles)");
+        if (c.d_tiles) hipFree(c.d_tiles);
+        c.d_tiles = nullptr;
+        c.d_tiles_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d_tiles), tiles.size() * sizeof(uint32_t)));
+        c.d_tiles_cap = wl.n_tiles;
     }
     if (wl.n_tiles) {
-        HIP_TRY(hipMemcpyAsync(s->d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c.d_tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));  // `tiles` is a local
     }
-    wl.tile_xy = s->d_tiles;
-    s->plan_key = key;
-    s->plan_wl = wl;
-    s->plan_scattered = scattered;
-    s->plan_valid = true;
+    wl.tile_xy = c.d_tiles;
+    c.plan_key = key;
+    c.plan_wl = wl;
+    c.plan_scattered = scattered;
+    c.plan_valid = true;
     return RT_OK;
 }
 
@@ -481,7 +512,7 @@ uint32_t shard_grid(const rt_scene *s, const Shards &sh, uint64_t n, uint32_t bl
 }
 
 // Shard layout of a batch of n camera-ray items (ns samples per pixel).
-Shards plan_shards(const rt_scene *s, uint64_t n, uint32_t ns) {
+Shards plan_shards(const RenderCtx &c, uint64_t n, uint32_t ns) {
     Shards sh{};
     sh.granule = 64u * ns;  // 64 consecutive pixels per deal
     const uint64_t n_gran = (n + sh.granule - 1) / sh.granule;
@@ -489,8 +520,8 @@ Shards plan_shards(const rt_scene *s, uint64_t n, uint32_t ns) {
     if (k >= 8) k &= ~7u;  // whole shards per XCD (blocks are dealt round-robin over the 8 XCDs)
     sh.count = k;
     if (k == 1) sh.granule = ns;  // no padding items in small batches
-    sh.node_cap = s->np.capacity / k;
-    sh.shadow_cap = s->sp.capacity / k;
+    sh.node_cap = c.np.capacity / k;
+    sh.shadow_cap = c.sp.capacity / k;
     return sh;
 }
 
@@ -501,18 +532,76 @@ uint32_t stack_lds_bytes(const rt_scene *s) {
     return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + s->dev.n_top_nodes * static_cast<uint32_t>(sizeof(BvhNode)) + extra;
 }
 
-Shards single_shard(const rt_scene *s) { return Shards{1u, s->np.capacity, s->sp.capacity, 1u}; }
+Shards single_shard(const RenderCtx &c) { return Shards{1u, c.np.capacity, c.sp.capacity, 1u}; }
 
-}  // namespace
 
-extern "C" {
+// Entry points never unwind across the boundary, and run with the scene's device current (restored on exit).
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device) {
+        HIP_TRY(hipGetDevice(&prev));
+        if (prev != device) {
+            HIP_TRY(hipSetDevice(device));
+            switched = true;
+        }
+        return RT_OK;
+    }
+    ~DeviceScope() {
+        if (switched) hipSetDevice(prev);
+    }
+};
+template <typename F>
+int guarded(F fn) {
+    try {
+        return fn();
+    } catch (const std::bad_alloc &) {
+        return fail(RT_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(RT_ERR_INVALID, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(RT_ERR_INVALID, "internal error");
+    }
+}
+template <typename F>
+int guarded_on(rt_scene *s, F fn) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    return guarded([&]() -> int {
+        DeviceScope scope;
+        if (int rc = scope.enter(s->device)) return rc;
+        return fn();
+    });
+}
 
-const char *rt_last_error(void) { return g_error.c_str(); }
-const char *rt_version(void) { return "mi355rt 0.1 (gfx950, f64 wavefront)"; }
+// RAII for the temporaries of an entry point
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        HIP_TRY(hipMalloc(&p, bytes));
+        return RT_OK;
+    }
+    template <typename T>
+    T *as() const { return static_cast<T *>(p); }
+};
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() {
+        if (a) hipEventDestroy(a);
+        if (b) hipEventDestroy(b);
+    }
+};
 
-int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
+int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     if (!d || !out) return fail(RT_ERR_INVALID, "null argument");
     *out = nullptr;
+    // a count above zero needs its array
+    if ((d->n_prims && (!d->prim_type || !d->prim_material || !d->prim_transform || !d->prim_param || !d->prim_normal || !d->prim_tri)) ||
+        (d->n_transforms && (!d->world || !d->inv_world)) || (d->n_tris && (!d->tri_pos || !d->tri_nrm || !d->tri_uv)) ||
+        (d->n_materials && !d->materials) || (d->n_lights && !d->lights) || (d->n_textures && !d->textures))
+        return fail(RT_ERR_INVALID, "null array with a non-zero count in rt_scene_desc");
     const rt_render_options &o = d->opts;
     if (o.width == 0 || o.height == 0 || o.samples_per_pixel == 0)
         return fail(RT_ERR_INVALID, "width, height and samples_per_pixel must be positive");
@@ -768,7 +857,23 @@ int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
     return RT_OK;
 }
 
-void rt_scene_destroy(rt_scene *scene) { delete scene; }
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+const char *rt_version(void) { return "mi355rt 0.2 (gfx950, f64 wavefront)"; }
+
+int rt_scene_create(const rt_scene_desc *d, rt_scene **out) {
+    return guarded([&]() -> int { return scene_create_impl(d, out); });
+}
+
+void rt_scene_destroy(rt_scene *scene) {
+    try {
+        delete scene;
+    } catch (...) {
+    }
+}
 
 int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes) {
     if (!scene) return fail(RT_ERR_INVALID, "null scene");
@@ -780,19 +885,21 @@ int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes) {
 int rt_shard_tiles(const rt_render_options *opts, const rt_render_params *params, uint32_t *tile_xy, uint32_t cap,
                    uint32_t *n_tiles, uint32_t *tile_w, uint32_t *tile_h) {
     if (!opts || !n_tiles) return fail(RT_ERR_INVALID, "null argument");
-    std::vector<uint32_t> tiles;
-    WorkList wl{};
-    int rc = plan_tiles(*opts, params, &tiles, &wl);
-    if (rc) return rc;
-    *n_tiles = wl.n_tiles;
-    if (tile_w) *tile_w = wl.tile_w;
-    if (tile_h) *tile_h = wl.tile_h;
-    if (tile_xy)
-        for (uint32_t i = 0; i < wl.n_tiles && i < cap; ++i) {
-            tile_xy[2 * i] = tiles[2 * i];
-            tile_xy[2 * i + 1] = tiles[2 * i + 1];
-        }
-    return RT_OK;
+    return guarded([&]() -> int {
+        std::vector<uint32_t> tiles;
+        WorkList wl{};
+        int rc = plan_tiles(*opts, params, &tiles, &wl);
+        if (rc) return rc;
+        *n_tiles = wl.n_tiles;
+        if (tile_w) *tile_w = wl.tile_w;
+        if (tile_h) *tile_h = wl.tile_h;
+        if (tile_xy)
+            for (uint32_t i = 0; i < wl.n_tiles && i < cap; ++i) {
+                tile_xy[2 * i] = tiles[2 * i];
+                tile_xy[2 * i + 1] = tiles[2 * i + 1];
+            }
+        return RT_OK;
+    });
 }
 
 int rt_scene_info(rt_scene *scene, uint64_t *out8) {
@@ -803,50 +910,47 @@ int rt_scene_info(rt_scene *scene, uint64_t *out8) {
     out8[3] = scene->scene_bytes;
     out8[4] = scene->dev.n_bounded;
     out8[5] = scene->dev.n_planes;
-    out8[6] = scene->np.capacity;
-    out8[7] = scene->sp.capacity;
+    out8[6] = scene->ctx.np.capacity;
+    out8[7] = scene->ctx.sp.capacity;
     return RT_OK;
 }
 
-int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_accum, uint64_t *ray_count,
-                     rt_render_stats *stats, void *stream_v) {
-    return rt_render_aov_device(s, params, d_rgb_accum, nullptr, nullptr, ray_count, stats, stream_v);
-}
+}  // extern "C"
 
-int rt_render_aov_device(rt_scene *s, const rt_render_params *params, double *d_rgb_accum, double *d_albedo_accum,
-                         double *d_normal, uint64_t *ray_count, rt_render_stats *stats, void *stream_v) {
-    if (!s || !d_rgb_accum) return fail(RT_ERR_INVALID, "null argument");
+namespace {
+
+// One render call in the wavefront state `ctx` (the scene's own pools, or the static scratch): batches of camera rays
+// through raygen -> (trace, expand) per level -> shadow -> resolve per level -> accumulate.  The scene's device is
+// current.  Allocates nothing itself when `stats` is NULL and the plan fits ctx's tile list (events are only created
+// for statistics).
+int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, double *d_rgb_accum, double *d_albedo_accum,
+                double *d_normal, uint64_t *ray_count, rt_render_stats *stats, hipStream_t stream) {
     const uint32_t aov = (d_albedo_accum || d_normal) ? 1u : 0u;
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    int rc = ensure_pools(s);
-    if (rc) return rc;
+    int rc;
     CallPlan plan;
-    if ((rc = plan_call(s, params, &plan, stream))) return rc;
+    if ((rc = plan_call(s, ctx, params, &plan, stream))) return rc;
     const WorkList &wl = plan.wl;
     const bool count_work = params && (params->flags & RT_FLAG_COUNT_WORK);
     const uint32_t max_depth = s->dev.opts.max_depth;
-    const NodePool &np = s->np;
-    const ShadowPool &sp = s->sp;
+    const NodePool &np = ctx.np;
+    const ShadowPool &sp = ctx.sp;
+    Counters *d_ctr = ctx.d_ctr;
 
     rt_render_stats st{};
     EventTimer timer;
     timer.enabled = stats != nullptr;
     timer.stream = stream;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    EventPair call_ev;
     if (stats) {
-        hipEventCreate(&ev_begin);
-        hipEventCreate(&ev_end);
-        hipEventRecord(ev_begin, stream);
+        HIP_TRY(hipEventCreate(&call_ev.a));
+        HIP_TRY(hipEventCreate(&call_ev.b));
+        HIP_TRY(hipEventRecord(call_ev.a, stream));
     }
 
     uint64_t item0 = 0;
     double call_max_nodes = 0.0, call_max_shadows = 0.0;
     // first batch: modest guess, later batches sized from the measured expansion
-    uint64_t batch = std::min<uint64_t>(plan.total_items, std::max<uint64_t>(wl.ns, np.capacity / 64));
-    if (s->est_nodes_per_item > 0.0) {
-        double fit = std::min(np.capacity / s->est_nodes_per_item, sp.capacity / std::max(s->est_shadows_per_item, 1e-9));
-        batch = std::min<uint64_t>(plan.total_items, std::max<uint64_t>(wl.ns, static_cast<uint64_t>(0.7 * fit)));
-    }
+    uint64_t batch = first_batch_items(ctx, plan.total_items, wl.ns);
     const uint32_t gmax = static_cast<uint32_t>(s->n_cus) * 8u;
     while (item0 < plan.total_items) {
         uint64_t n = std::min<uint64_t>(batch, plan.total_items - item0);
@@ -854,57 +958,57 @@ int rt_render_aov_device(rt_scene *s, const rt_render_params *params, double *d_
         n -= n % wl.ns;
         if (n == 0) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's samples");
         const uint32_t n32 = static_cast<uint32_t>(n), i0 = static_cast<uint32_t>(item0);
-        const Shards sh = plan_shards(s, n, wl.ns);
+        const Shards sh = plan_shards(ctx, n, wl.ns);
         // traversal: 48 blocks per CU, four resident -- the hardware deals out the rest as blocks finish, which evens out
         // rays of very different cost (4 persistent blocks per CU: scene.json +7 %, the 1M-triangle scene +37 %)
         const uint32_t g_level = shard_grid(s, sh, static_cast<uint64_t>(s->n_cus) * 48u * BLOCK, 48);
         const uint32_t g_wide = shard_grid(s, sh, static_cast<uint64_t>(gmax) * BLOCK, 8);
 
         timer.begin(CLS_MISC);
-        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, stream, s->d_ctr, sh, n32);
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, stream, d_ctr, sh, n32);
         timer.end();
         timer.begin(CLS_RAYGEN);
-        hipLaunchKernelGGL(k_raygen, dim3(shard_grid(s, sh, n, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, s->d_ctr, sh, i0, n32);
+        hipLaunchKernelGGL(k_raygen, dim3(shard_grid(s, sh, n, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, d_ctr, sh, i0, n32);
         timer.end();
         if (max_depth > 0) {
             for (uint32_t level = 0; level < max_depth; ++level) {
                 const uint32_t g = level == 0 ? shard_grid(s, sh, n, 48) : g_level;
                 timer.begin(CLS_CLOSEST);
-                if (count_work) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level, stack_entries(s));
-                else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, s->d_ctr, sh, level, stack_entries(s));
+                if (count_work) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s));
+                else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s));
                 timer.end();
                 timer.begin(CLS_EXPAND);
-                hipLaunchKernelGGL(k_build_live, dim3(level == 0 ? shard_grid(s, sh, n / 4 + 1, 8) : g_wide), dim3(BLOCK), 0, stream, np, s->d_ctr, sh, level);
+                hipLaunchKernelGGL(k_build_live, dim3(level == 0 ? shard_grid(s, sh, n / 4 + 1, 8) : g_wide), dim3(BLOCK), 0, stream, np, d_ctr, sh, level);
                 const uint32_t ge = level == 0 ? shard_grid(s, sh, n, 8) : g_wide;
-                if (count_work) hipLaunchKernelGGL(k_expand<true>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, s->d_ctr, sh, level);
-                else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, s->d_ctr, sh, level);
-                hipLaunchKernelGGL(k_advance_level, dim3(1), dim3(64), 0, stream, s->d_ctr, sh, level);
+                if (count_work) hipLaunchKernelGGL(k_expand<true>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, d_ctr, sh, level);
+                else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, d_ctr, sh, level);
+                hipLaunchKernelGGL(k_advance_level, dim3(1), dim3(64), 0, stream, d_ctr, sh, level);
                 timer.end();
             }
             timer.begin(CLS_SHADOW);
             if (count_work)
-                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, s->d_ctr, sh, 0u, stack_entries(s));
+                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, d_ctr, sh, 0u, stack_entries(s));
             else
-                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, s->d_ctr, sh, 0u, stack_entries(s));
+                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, d_ctr, sh, 0u, stack_entries(s));
             timer.end();
             for (uint32_t level = max_depth; level-- > 0;) {
                 timer.begin(CLS_RESOLVE);
                 const dim3 gr(level == 0 ? shard_grid(s, sh, n, 8) : g_wide);
-                if (level > 0) hipLaunchKernelGGL(k_resolve<true>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, level, 0u);  // camera rays are colour nodes
-                hipLaunchKernelGGL(k_resolve<false>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, s->d_ctr, sh, level, aov);
+                if (level > 0) hipLaunchKernelGGL(k_resolve<true>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, d_ctr, sh, level, 0u);  // camera rays are colour nodes
+                hipLaunchKernelGGL(k_resolve<false>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, d_ctr, sh, level, aov);
                 timer.end();
             }
             timer.begin(CLS_ACCUM);
-            hipLaunchKernelGGL(k_accumulate, dim3(shard_grid(s, sh, n / wl.ns, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, s->d_ctr, sh,
+            hipLaunchKernelGGL(k_accumulate, dim3(shard_grid(s, sh, n / wl.ns, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, d_ctr, sh,
                                d_rgb_accum, d_albedo_accum, d_normal);
             timer.end();
         }
-        HIP_TRY(hipMemcpyAsync(s->h_ctr, s->d_ctr, sh.count * sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(ctx.h_ctr, d_ctr, sh.count * sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
         Counters c{};  // sum over shards
         for (uint32_t k = 0; k < sh.count; ++k) {
-            const Counters &ck = s->h_ctr[k];
+            const Counters &ck = ctx.h_ctr[k];
             for (uint32_t l = 0; l <= MAX_LEVELS; ++l) c.level_count[l] += ck.level_count[l];
             c.node_alloc += ck.node_alloc;
             c.shadow_alloc += ck.shadow_alloc;
@@ -923,26 +1027,24 @@ int rt_render_aov_device(rt_scene *s, const rt_render_params *params, double *d_
             for (uint32_t q = 0; q < 4; ++q) c.leaf_lanes[q] += ck.leaf_lanes[q];
             c.wave_max_steps = std::max(c.wave_max_steps, ck.wave_max_steps);
         }
-        if (count_work && std::getenv("MI355RT_CENSUS"))
+        if (count_work && std::getenv("MI355RT_CENSUS")) {
             std::fprintf(stderr, "[mi355rt census] closest kernel, wave level: %llu node visits, %llu leaf rounds over %llu waves (all levels); busiest wave %llu node visits\n",
                          c.wave_node_steps, c.wave_leaf_rounds, c.wave_iterations, c.wave_max_steps);
-        if (count_work && std::getenv("MI355RT_CENSUS")) {
             std::fprintf(stderr, "[mi355rt census] leaf rounds by content (T S C X=exact box):");
             for (uint32_t q = 0; q < 16; ++q)
                 if (c.leaf_census[q]) std::fprintf(stderr, " %s%s%s%s=%llu", q & 1 ? "T" : "", q & 2 ? "S" : "", q & 4 ? "C" : "", q & 8 ? "X" : "", c.leaf_census[q]);
             std::fprintf(stderr, "\n[mi355rt census] leaf-round lanes %llu, exact-box lanes %llu, hit lanes %llu\n", c.leaf_lanes[0], c.leaf_lanes[1], c.leaf_lanes[2]);
-        }
-        if (count_work && std::getenv("MI355RT_CENSUS"))
             for (uint32_t l = 0; l < max_depth && l < MAX_LEVELS; ++l)
                 std::fprintf(stderr, "[mi355rt census] level %u: colour %llu illum %llu miss %llu no-emit %llu\n", l, c.census[l][0],
                              c.census[l][1], c.census[l][2], c.census[l][3]);
+        }
         float cls_ms[CLS_COUNT] = {0};
         uint32_t cls_n[CLS_COUNT] = {0};
         timer.collect(cls_ms, cls_n, CLS_COUNT);
         if (c.overflow) {
             if (n <= wl.ns) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's ray tree");
             batch = std::max<uint64_t>(wl.ns, (n / 2) - (n / 2) % wl.ns);
-            s->est_nodes_per_item = 0.0;
+            ctx.est_nodes_per_item = 0.0;
             st.retries += 1;
             continue;  // re-run the same range with a smaller batch; nothing was accumulated
         }
@@ -973,195 +1075,227 @@ int rt_render_aov_device(rt_scene *s, const rt_render_params *params, double *d_
         // provoke an overflow + re-run at the start of the next frame
         call_max_nodes = std::max(call_max_nodes, static_cast<double>(c.node_alloc) / static_cast<double>(n));
         call_max_shadows = std::max(call_max_shadows, static_cast<double>(c.shadow_alloc) / static_cast<double>(n));
-        s->est_nodes_per_item = std::max(s->est_nodes_per_item, call_max_nodes);
-        s->est_shadows_per_item = std::max(s->est_shadows_per_item, call_max_shadows);
-        double fit = std::min(np.capacity / std::max(s->est_nodes_per_item, 1.0),
-                              sp.capacity / std::max(s->est_shadows_per_item, 1e-9));
+        ctx.est_nodes_per_item = std::max(ctx.est_nodes_per_item, call_max_nodes);
+        ctx.est_shadows_per_item = std::max(ctx.est_shadows_per_item, call_max_shadows);
+        double fit = std::min(np.capacity / std::max(ctx.est_nodes_per_item, 1.0),
+                              sp.capacity / std::max(ctx.est_shadows_per_item, 1e-9));
         batch = std::max<uint64_t>(wl.ns, static_cast<uint64_t>(0.7 * fit));
         item0 += n;
     }
     if (call_max_nodes > 0.0) {  // forget stale maxima of earlier calls (other windows / shards)
-        s->est_nodes_per_item = call_max_nodes;
-        s->est_shadows_per_item = call_max_shadows;
+        ctx.est_nodes_per_item = call_max_nodes;
+        ctx.est_shadows_per_item = call_max_shadows;
     }
     st.ray_count = st.closest_rays + st.shadow_rays;
     if (stats) {
-        hipEventRecord(ev_end, stream);
-        hipEventSynchronize(ev_end);
-        hipEventElapsedTime(&st.ms_total, ev_begin, ev_end);
-        hipEventDestroy(ev_begin);
-        hipEventDestroy(ev_end);
+        HIP_TRY(hipEventRecord(call_ev.b, stream));
+        HIP_TRY(hipEventSynchronize(call_ev.b));
+        hipEventElapsedTime(&st.ms_total, call_ev.a, call_ev.b);
         *stats = st;
     }
     if (ray_count) *ray_count += st.ray_count;
     return RT_OK;
 }
 
+uint32_t grid_1d(uint64_t n, uint32_t cap) { return static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>((n + BLOCK - 1) / BLOCK, cap))); }
+
+}  // namespace
+
+extern "C" {
+
+int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_accum, uint64_t *ray_count,
+                     rt_render_stats *stats, void *stream_v) {
+    return rt_render_aov_device(s, params, d_rgb_accum, nullptr, nullptr, ray_count, stats, stream_v);
+}
+
+int rt_render_aov_device(rt_scene *s, const rt_render_params *params, double *d_rgb_accum, double *d_albedo_accum,
+                         double *d_normal, uint64_t *ray_count, rt_render_stats *stats, void *stream_v) {
+    if (!s || !d_rgb_accum) return fail(RT_ERR_INVALID, "null argument");
+    return guarded_on(s, [&]() -> int {
+        if (int rc = ensure_pools(s)) return rc;
+        return render_impl(s, s->ctx, params, d_rgb_accum, d_albedo_accum, d_normal, ray_count, stats, static_cast<hipStream_t>(stream_v));
+    });
+}
+
+
 int rt_render_aov(rt_scene *s, const rt_render_params *params, double *rgb_accum, double *albedo, double *normal,
                   uint64_t *ray_count, rt_render_stats *stats) {
-    if (!s) return fail(RT_ERR_INVALID, "null scene");
-    const uint64_t n3 = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height * 3;
-    const double inv_spp = 1.0 / static_cast<double>(s->dev.opts.samples_per_pixel);
-    double *d_buf = nullptr;  // [rgb | albedo | normal]
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_buf), 3 * n3 * sizeof(double)));
-    int rc = RT_OK;
-    do {
-        if (hipMemset(d_buf, 0, 3 * n3 * sizeof(double)) != hipSuccess) {
-            rc = fail(RT_ERR_DEVICE, "hipMemset failed");
-            break;
-        }
-        if ((rc = rt_render_aov_device(s, params, d_buf, albedo ? d_buf + n3 : nullptr, normal ? d_buf + 2 * n3 : nullptr, ray_count,
-                                       stats, nullptr)))
-            break;
-        hipError_t e = hipSuccess;
-        if (rgb_accum) e = hipMemcpy(rgb_accum, d_buf, n3 * sizeof(double), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && albedo) e = hipMemcpy(albedo, d_buf + n3, n3 * sizeof(double), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && normal) e = hipMemcpy(normal, d_buf + 2 * n3, n3 * sizeof(double), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            rc = fail(RT_ERR_DEVICE, std::string("rt_render_aov: ") + hipGetErrorString(e));
-            break;
-        }
+    return guarded_on(s, [&]() -> int {
+        const uint64_t n3 = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height * 3;
+        const double inv_spp = 1.0 / static_cast<double>(s->dev.opts.samples_per_pixel);
+        DevBuf buf;  // [rgb | albedo | normal]
+        if (int rc = buf.alloc(3 * n3 * sizeof(double))) return rc;
+        double *d_buf = buf.as<double>();
+        HIP_TRY(hipMemset(d_buf, 0, 3 * n3 * sizeof(double)));
+        if (int rc = ensure_pools(s)) return rc;
+        if (int rc = render_impl(s, s->ctx, params, d_buf, albedo ? d_buf + n3 : nullptr, normal ? d_buf + 2 * n3 : nullptr, ray_count, stats, nullptr)) return rc;
+        if (rgb_accum) HIP_TRY(hipMemcpy(rgb_accum, d_buf, n3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (albedo) HIP_TRY(hipMemcpy(albedo, d_buf + n3, n3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (normal) HIP_TRY(hipMemcpy(normal, d_buf + 2 * n3, n3 * sizeof(double), hipMemcpyDeviceToHost));
         if (albedo && s->dev.opts.samples_per_pixel != 1)  // :616 `albedo *= inv_samples`, :619 clamp (one sample: get_color's own clamp)
             for (uint64_t i = 0; i < n3; ++i) {
                 const double a = albedo[i] * inv_spp;
                 albedo[i] = a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);
             }
-    } while (false);
-    hipFree(d_buf);
-    return rc;
+        return RT_OK;
+    });
 }
 
 int rt_tonemap_device(rt_scene *s, const double *d_rgb_accum, uint8_t *d_rgba8, void *stream_v) {
     if (!s || !d_rgb_accum || !d_rgba8) return fail(RT_ERR_INVALID, "null argument");
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    const uint32_t n = s->dev.opts.width * s->dev.opts.height;
-    hipLaunchKernelGGL(k_tonemap, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, stream, n, s->dev.opts.samples_per_pixel, d_rgb_accum,
-                       d_rgba8);
-    HIP_TRY(hipGetLastError());
-    return RT_OK;
+    return guarded_on(s, [&]() -> int {
+        hipStream_t stream = static_cast<hipStream_t>(stream_v);
+        const uint32_t n = s->dev.opts.width * s->dev.opts.height;
+        hipLaunchKernelGGL(k_tonemap, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, stream, n, s->dev.opts.samples_per_pixel, d_rgb_accum, d_rgba8);
+        HIP_TRY(hipGetLastError());
+        return RT_OK;
+    });
 }
 
 int rt_render(rt_scene *s, const rt_render_params *params, double *rgb_accum, uint8_t *rgba8, uint64_t *ray_count,
               rt_render_stats *stats) {
-    if (!s) return fail(RT_ERR_INVALID, "null scene");
-    const uint64_t n = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height;
-    double *d_acc = nullptr;
-    uint8_t *d_rgba = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_acc), n * 3 * sizeof(double)));
-    int rc = RT_OK;
-    do {
-        if (hipMemset(d_acc, 0, n * 3 * sizeof(double)) != hipSuccess) {
-            rc = fail(RT_ERR_DEVICE, "hipMemset failed");
-            break;
-        }
-        if ((rc = rt_render_device(s, params, d_acc, ray_count, stats, nullptr))) break;
-        if (rgb_accum && hipMemcpy(rgb_accum, d_acc, n * 3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
-            rc = fail(RT_ERR_DEVICE, "copy of the accumulation buffer failed");
-            break;
-        }
+    return guarded_on(s, [&]() -> int {
+        const uint64_t n = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height;
+        DevBuf acc, img;
+        if (int rc = acc.alloc(n * 3 * sizeof(double))) return rc;
+        HIP_TRY(hipMemset(acc.p, 0, n * 3 * sizeof(double)));
+        if (int rc = ensure_pools(s)) return rc;
+        if (int rc = render_impl(s, s->ctx, params, acc.as<double>(), nullptr, nullptr, ray_count, stats, nullptr)) return rc;
+        if (rgb_accum) HIP_TRY(hipMemcpy(rgb_accum, acc.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
         if (rgba8) {
-            if (hipMalloc(reinterpret_cast<void **>(&d_rgba), n * 4) != hipSuccess) {
-                rc = fail(RT_ERR_DEVICE, "hipMalloc failed");
-                break;
-            }
-            if ((rc = rt_tonemap_device(s, d_acc, d_rgba, nullptr))) break;
-            if (hipMemcpy(rgba8, d_rgba, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
-                rc = fail(RT_ERR_DEVICE, "copy of the image failed");
-                break;
-            }
+            if (int rc = img.alloc(n * 4)) return rc;
+            hipLaunchKernelGGL(k_tonemap, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, static_cast<uint32_t>(n), s->dev.opts.samples_per_pixel,
+                               acc.as<double>(), img.as<uint8_t>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(rgba8, img.p, n * 4, hipMemcpyDeviceToHost));
         }
-    } while (false);
-    hipFree(d_acc);
-    if (d_rgba) hipFree(d_rgba);
-    return rc;
+        return RT_OK;
+    });
+}
+
+int rt_render_progressive(rt_scene *s, const rt_render_params *params, uint32_t n_passes, uint32_t *argb, rt_progress_fn on_pass,
+                          void *user, double *rgb_accum, uint64_t *ray_count) {
+    if (!argb) return fail(RT_ERR_INVALID, "null argument");
+    return guarded_on(s, [&]() -> int {
+        rt_render_params p{};
+        if (params) p = *params;
+        if (p.shard_count > 1) return fail(RT_ERR_INVALID, "rt_render_progressive deals the tiles itself: shard_count must be 0 or 1");
+        if (n_passes == 0) n_passes = 1;
+        const uint64_t n = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height;
+        DevBuf acc, img;
+        if (int rc = acc.alloc(n * 3 * sizeof(double))) return rc;
+        if (int rc = img.alloc(n * 4)) return rc;
+        HIP_TRY(hipMemset(acc.p, 0, n * 3 * sizeof(double)));
+        HIP_TRY(hipMemset(img.p, 0, n * 4));  // the reference's buffer starts as zeros (:800), not as opaque black
+        if (int rc = ensure_pools(s)) return rc;
+        uint64_t rays = 0;
+        for (uint32_t pass = 0; pass < n_passes; ++pass) {
+            rt_render_params q = p;
+            if (n_passes > 1) {
+                q.shard_index = pass;
+                q.shard_count = n_passes;
+                if (!q.tile_size) q.tile_size = 8;
+            }
+            if (int rc = render_impl(s, s->ctx, &q, acc.as<double>(), nullptr, nullptr, &rays, nullptr, nullptr)) return rc;
+            // the pixels of this pass are complete (all their samples): to_argb_u32 of their colour (:816-819)
+            const WorkList &wl = s->ctx.plan_wl;
+            const uint64_t npx = static_cast<uint64_t>(wl.n_tiles) * wl.tile_w * wl.tile_h;
+            if (npx)
+                hipLaunchKernelGGL(k_tonemap_argb_tiles, dim3(grid_1d(npx, 2048)), dim3(BLOCK), 0, nullptr, s->dev, wl, wl.ns, acc.as<double>(), img.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(argb, img.p, n * 4, hipMemcpyDeviceToHost));
+            if (on_pass && on_pass(user, pass + 1, n_passes, rays) != 0) break;  // the caller closed its window (:865)
+        }
+        if (rgb_accum) HIP_TRY(hipMemcpy(rgb_accum, acc.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (ray_count) *ray_count += rays;
+        return RT_OK;
+    });
 }
 
 int rt_query_primary(rt_scene *s, uint32_t *prim_id, double *t, double *normal3) {
-    if (!s || !prim_id || !t || !normal3) return fail(RT_ERR_INVALID, "null argument");
-    int rc = ensure_pools(s);
-    if (rc) return rc;
-    rt_render_params prm{};
-    prm.s0 = 0;
-    prm.s1 = 1;
-    CallPlan plan;
-    if ((rc = plan_call(s, &prm, &plan, nullptr))) return rc;
-    const uint64_t npx = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height;
-    uint32_t *d_id = nullptr;
-    double *d_t = nullptr, *d_n = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_id), npx * 4));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_t), npx * 8));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_n), npx * 24));
-    uint64_t item0 = 0;
-    while (item0 < plan.total_items) {
-        const uint32_t n = static_cast<uint32_t>(std::min<uint64_t>(plan.total_items - item0, s->np.capacity));
-        const Shards one = single_shard(s);
-        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, one, n);
-        hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, s->d_ctr, one,
-                           static_cast<uint32_t>(item0), n);
-        hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid_for(s, n, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, s->np, s->d_ctr, one,
-                           0u, stack_entries(s));
-        hipLaunchKernelGGL(k_primary_aov, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, s->np, n, d_id, d_t,
-                           d_n);
-        item0 += n;
-    }
-    hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpy(prim_id, d_id, npx * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(t, d_t, npx * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(normal3, d_n, npx * 24, hipMemcpyDeviceToHost);
-    hipFree(d_id);
-    hipFree(d_t);
-    hipFree(d_n);
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, std::string("rt_query_primary: ") + hipGetErrorString(e));
-    return RT_OK;
+    if (!prim_id || !t || !normal3) return fail(RT_ERR_INVALID, "null argument");
+    return guarded_on(s, [&]() -> int {
+        if (int rc = ensure_pools(s)) return rc;
+        RenderCtx &ctx = s->ctx;
+        rt_render_params prm{};
+        prm.s0 = 0;
+        prm.s1 = 1;
+        CallPlan plan;
+        if (int rc = plan_call(s, ctx, &prm, &plan, nullptr)) return rc;
+        const uint64_t npx = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height;
+        DevBuf b_id, b_t, b_n;
+        if (int rc = b_id.alloc(npx * 4)) return rc;
+        if (int rc = b_t.alloc(npx * 8)) return rc;
+        if (int rc = b_n.alloc(npx * 24)) return rc;
+        uint64_t item0 = 0;
+        while (item0 < plan.total_items) {
+            const uint32_t n = static_cast<uint32_t>(std::min<uint64_t>(plan.total_items - item0, ctx.np.capacity));
+            const Shards one = single_shard(ctx);
+            hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, ctx.d_ctr, one, n);
+            hipLaunchKernelGGL(k_raygen, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, ctx.np, ctx.d_ctr, one, static_cast<uint32_t>(item0), n);
+            hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid_for(s, n, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, ctx.np, ctx.d_ctr, one, 0u,
+                               stack_entries(s));
+            hipLaunchKernelGGL(k_primary_aov, dim3(grid_for(s, n, 8)), dim3(BLOCK), 0, nullptr, s->dev, plan.wl, ctx.np, n, b_id.as<uint32_t>(), b_t.as<double>(),
+                               b_n.as<double>());
+            item0 += n;
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(prim_id, b_id.p, npx * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(t, b_t.p, npx * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(normal3, b_n.p, npx * 24, hipMemcpyDeviceToHost));
+        return RT_OK;
+    });
 }
 
 int rt_trace_rays(rt_scene *s, uint32_t n, const double *origin, const double *dir, const double *tmax, int shadow,
                   uint32_t *prim_id, double *t) {
-    if (!s || !origin || !dir || !prim_id || (shadow && !tmax)) return fail(RT_ERR_INVALID, "null argument");
-    int rc = ensure_pools(s);
-    if (rc) return rc;
-    const NodePool &np = s->np;
-    std::vector<double> col;
-    std::vector<uint32_t> meta;
-    uint32_t done = 0;
-    while (done < n) {
-        const uint32_t m = std::min<uint32_t>(n - done, np.capacity);
-        col.resize(2ull * m);
-        // the ray as the node pool holds it: (o.x, o.y) (o.z, d.x) (d.y, d.z)
-        auto put = [&](Vec2d *dst, const double *a, int ca, const double *b, int cb) -> hipError_t {
-            for (uint32_t i = 0; i < m; ++i) {
-                col[2ull * i] = a[3ull * (done + i) + ca];
-                col[2ull * i + 1] = b[3ull * (done + i) + cb];
+    if (!origin || !dir || !prim_id || (shadow && !tmax)) return fail(RT_ERR_INVALID, "null argument");
+    return guarded_on(s, [&]() -> int {
+        if (int rc = ensure_pools(s)) return rc;
+        RenderCtx &ctx = s->ctx;
+        const NodePool &np = ctx.np;
+        std::vector<double> col;
+        std::vector<uint32_t> meta;
+        uint32_t done = 0;
+        while (done < n) {
+            const uint32_t m = std::min<uint32_t>(n - done, np.capacity);
+            col.resize(2ull * m);
+            // the ray as the node pool holds it: (o.x, o.y) (o.z, d.x) (d.y, d.z)
+            auto put = [&](Vec2d *dst, const double *a, int ca, const double *b, int cb) -> hipError_t {
+                for (uint32_t i = 0; i < m; ++i) {
+                    col[2ull * i] = a[3ull * (done + i) + ca];
+                    col[2ull * i + 1] = b[3ull * (done + i) + cb];
+                }
+                return hipMemcpy(dst, col.data(), 2ull * m * sizeof(double), hipMemcpyHostToDevice);
+            };
+            HIP_TRY(put(np.r0, origin, 0, origin, 1));
+            HIP_TRY(put(np.r1, origin, 2, dir, 0));
+            HIP_TRY(put(np.r2, dir, 1, dir, 2));
+            meta.assign(m, 1u);  // depth 1 secondary
+            HIP_TRY(hipMemcpy(np.meta, meta.data(), m * 4, hipMemcpyHostToDevice));
+            const Shards one = single_shard(ctx);
+            hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, ctx.d_ctr, one, m);
+            if (shadow) {
+                HIP_TRY(hipMemcpy(np.t, tmax + done, m * sizeof(double), hipMemcpyHostToDevice));
+                hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, ctx.sp, ctx.d_ctr, one,
+                                   m, stack_entries(s));
+            } else {
+                hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, ctx.d_ctr, one, 0u,
+                                   stack_entries(s));
             }
-            return hipMemcpy(dst, col.data(), 2ull * m * sizeof(double), hipMemcpyHostToDevice);
-        };
-        HIP_TRY(put(np.r0, origin, 0, origin, 1));
-        HIP_TRY(put(np.r1, origin, 2, dir, 0));
-        HIP_TRY(put(np.r2, dir, 1, dir, 2));
-        meta.assign(m, 1u);  // depth 1 secondary
-        HIP_TRY(hipMemcpy(np.meta, meta.data(), m * 4, hipMemcpyHostToDevice));
-        const Shards one = single_shard(s);
-        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, s->d_ctr, one, m);
-        if (shadow) {
-            HIP_TRY(hipMemcpy(np.t, tmax + done, m * sizeof(double), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, s->sp,
-                               s->d_ctr, one, m, stack_entries(s));
-        } else {
-            hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, s->d_ctr, one,
-                               0u, stack_entries(s));
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(prim_id + done, np.prim, m * 4, hipMemcpyDeviceToHost));
+            if (t) {
+                if (shadow) std::fill(t + done, t + done + m, 0.0);
+                else HIP_TRY(hipMemcpy(t + done, np.t, m * sizeof(double), hipMemcpyDeviceToHost));
+            }
+            done += m;
         }
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(prim_id + done, np.prim, m * 4, hipMemcpyDeviceToHost));
-        if (t) {
-            if (shadow) std::fill(t + done, t + done + m, 0.0);
-            else HIP_TRY(hipMemcpy(t + done, np.t, m * sizeof(double), hipMemcpyDeviceToHost));
-        }
-        done += m;
-    }
-    if (t && !shadow)
-        for (uint32_t i = 0; i < n; ++i)
-            if (prim_id[i] == RT_NO_HIT) t[i] = 0.0;
-    return RT_OK;
+        if (t && !shadow)
+            for (uint32_t i = 0; i < n; ++i)
+                if (prim_id[i] == RT_NO_HIT) t[i] = 0.0;
+        return RT_OK;
+    });
 }
 
 }  // extern "C"

@@ -1,9 +1,10 @@
 // rt_internal.h -- device-resident data layout shared by host and kernels.
 //
 // Everything the wavefront kernels touch lives in HBM as flat arrays:
-//   * scene (read-only): BVH nodes (128 B, both children's boxes inline),
-//     leaf primitive records in BVH-leaf order (128 B: the primitive's own
-//     world AABB + object-space geometry), per-primitive shading records in
+//   * scene (read-only): BVH nodes (32 B: both children's boxes as 16-bit fixed
+//     point + two child references), leaf primitive records in BVH-leaf order
+//     (128 B: the primitive's own world AABB + object-space geometry),
+//     per-primitive shading records in
 //     primitive-ID order, transforms, materials, lights, textures;
 //   * wavefront state (per batch): SoA node pool (ray, hit/result, expansion
 //     info) and SoA shadow-ray pool, bump-allocated level by level.

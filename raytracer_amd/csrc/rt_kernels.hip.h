@@ -1305,6 +1305,31 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(uint32_t n_pixels, uint32_t s
     }
 }
 
+// raytrace_to_buffer's `image_buffer[index] = utils::to_argb_u32(color_data.color)` (:816-819, utils/mod.rs:14-19) for
+// the pixels of a work list's tiles (inside the window): colour = :614-621 of the accumulated sum.
+__global__ __launch_bounds__(BLOCK) void k_tonemap_argb_tiles(SceneDev sc, WorkList wl, uint32_t spp, const double *accum, uint32_t *argb) {
+    const uint32_t per_tile = wl.tile_w * wl.tile_h;
+    const uint64_t total = static_cast<uint64_t>(wl.n_tiles) * per_tile;
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(BLOCK) + threadIdx.x; i < total; i += static_cast<uint64_t>(gridDim.x) * BLOCK) {
+        const uint32_t tile = static_cast<uint32_t>(i / per_tile), pit = static_cast<uint32_t>(i % per_tile);
+        const uint32_t px = wl.tile_xy[2 * tile] + pit % wl.tile_w, py = wl.tile_xy[2 * tile + 1] + pit / wl.tile_w;
+        if (px < wl.x0 || px >= wl.x1 || py < wl.y0 || py >= wl.y1) continue;
+        const uint64_t p = static_cast<uint64_t>(py) * sc.opts.width + px;
+        d3 c = mk3(accum[3ull * p], accum[3ull * p + 1], accum[3ull * p + 2]);
+        if (spp != 1) c = sat01(c * (1.0 / static_cast<double>(spp)));
+        c = sat01(c);
+        const double e = 1.0 / GAMMA;
+        c = mk3(pow(c.x, e), pow(c.y, e), pow(c.z, e));
+        auto q = [](double v) -> uint32_t {  // `(c * 255.0) as u8`
+            const double x = v * 255.0;
+            if (!(x > 0.0)) return 0u;
+            if (x >= 255.0) return 255u;
+            return static_cast<uint32_t>(x);
+        };
+        argb[p] = (255u << 24) | (q(c.x) << 16) | (q(c.y) << 8) | q(c.z);
+    }
+}
+
 // primary-hit AOVs of level-0 nodes (one sample per pixel): id, t, shading normal
 __global__ __launch_bounds__(BLOCK) void k_primary_aov(SceneDev sc, WorkList wl, NodePool np, uint32_t n_items,
                                                       uint32_t *out_id, double *out_t, double *out_n) {

@@ -15,7 +15,10 @@ _LIB = None
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_set_pool_bytes", "rt_render_device", "rt_tonemap_device",
     "rt_render", "rt_render_aov_device", "rt_render_aov", "rt_query_primary", "rt_trace_rays", "rt_scene_info", "rt_last_error", "rt_version",
+    "rt_render_progressive",
 ]
+
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64)
 
 
 class DeviceError(RuntimeError):
@@ -63,6 +66,8 @@ def lib():
         l.rt_tonemap_device.restype = C.c_int
         l.rt_render.argtypes = [vp, C.POINTER(_abi.RenderParams), f64p, u8p, u64p, C.POINTER(_abi.RenderStats)]
         l.rt_render.restype = C.c_int
+        l.rt_render_progressive.argtypes = [vp, C.POINTER(_abi.RenderParams), C.c_uint32, u32p, PROGRESS_FN, vp, f64p, u64p]
+        l.rt_render_progressive.restype = C.c_int
         l.rt_query_primary.argtypes = [vp, u32p, f64p, f64p]
         l.rt_query_primary.restype = C.c_int
         l.rt_trace_rays.argtypes = [vp, C.c_uint32, f64p, f64p, f64p, C.c_int, u32p, f64p]
@@ -147,6 +152,22 @@ class DeviceScene:
             )
         )
         return int(count.value), stats
+
+    def render_progressive(self, n_passes, params=None, on_pass=None, want_accum=False):
+        """rt_render_progressive -> (argb[h,w] u32, rgb_sum or None, ray_count).  on_pass(argb_view, passes_done, n_passes, rays)
+        may return True to stop."""
+        params = params or _abi.RenderParams()
+        argb = np.zeros((self.height, self.width), np.uint32)
+        acc = np.zeros((self.height, self.width, 3), np.float64) if want_accum else None
+        count = C.c_uint64(0)
+
+        def trampoline(_user, done, total, rays):
+            return 1 if (on_pass and on_pass(argb, int(done), int(total), int(rays))) else 0
+
+        cb = PROGRESS_FN(trampoline)
+        _check(lib().rt_render_progressive(self._h, C.byref(params), int(n_passes), _p(argb, C.c_uint32), cb, None,
+                                           _p(acc, C.c_double) if want_accum else None, C.byref(count)))
+        return argb, acc, int(count.value)
 
     def tonemap_device(self, d_accum_ptr, d_rgba_ptr, stream=None):
         _check(lib().rt_tonemap_device(self._h, C.c_void_p(d_accum_ptr), C.c_void_p(d_rgba_ptr), C.c_void_p(stream or 0)))

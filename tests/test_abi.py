@@ -86,6 +86,25 @@ def test_scene_create_fails_loudly_without_a_gpu(libs):
         device.DeviceScene(s.desc)
 
 
+def test_null_arrays_are_invalid_not_faults(libs):
+    """a NULL array with a non-zero count in rt_scene_desc is RT_ERR_INVALID (checked before any device call,
+    so this runs without a GPU); a NULL descriptor likewise."""
+    import ctypes as C
+
+    from raytracer_amd import _abi, device, host
+
+    s = host.LoadedScene.from_file(os.path.join(ROOT, "scenes", "test.json"))
+    lib = device.lib()
+    h = C.c_void_p()
+    assert lib.rt_scene_create(None, C.byref(h)) == _abi.RT_ERR_INVALID
+    for field, ctype in (("prim_type", C.c_uint8), ("world", C.c_double), ("materials", _abi.Material), ("lights", _abi.Light), ("textures", _abi.Texture)):
+        d = _abi.SceneDesc.from_buffer_copy(s.desc.contents)
+        setattr(d, field, C.POINTER(ctype)())
+        assert lib.rt_scene_create(C.byref(d), C.byref(h)) == _abi.RT_ERR_INVALID, field
+        assert b"null array" in lib.rt_last_error()
+        assert not h.value
+
+
 def test_shard_tiles_partition_the_frame():
     """rt_shard_tiles is pure host code: the shards of a frame are disjoint and cover it."""
     import numpy as np
