@@ -208,6 +208,20 @@ int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes);
 int rt_render_device(rt_scene *scene, const rt_render_params *params, double *d_rgb_accum,
                      uint64_t *ray_count, rt_render_stats *stats, void *stream);
 
+/* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arithmetic, same kernels and the same results as
+ * rt_render_device, but the wavefront pools, counters and tile list live in a static device array of
+ * RT_NOALLOC_SCRATCH_BYTES inside the library (one copy per GPU the library runs on, held until the process ends)
+ * instead of the scene's hipMalloc'ed pool budget: the call allocates and frees nothing (no hipMalloc / hipFree, no
+ * events; no statistics are offered).  Limits: at most RT_NOALLOC_MAX_CAMERA_RAYS camera rays per call (window pixels
+ * x samples, after sharding) and 4096 tiles; larger calls fail with RT_ERR_NOMEM and a message -- split the window or
+ * the sample range.  Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two host
+ * threads, two streams) race; serialise them.  The array keeps the last call's contents; the library resets what must
+ * start at zero (the batch counters) itself. */
+#define RT_NOALLOC_SCRATCH_BYTES (128ull << 20)
+#define RT_NOALLOC_MAX_CAMERA_RAYS (1u << 18)
+int rt_render_device_noalloc(rt_scene *scene, const rt_render_params *params, double *d_rgb_accum, uint64_t *ray_count,
+                             void *stream);
 
 /* As rt_render_device, plus the other two members of the ColorData that screen_raycast returns
  * (src/render/mod.rs:16-20, src/render/raytracing_scene.rs:598-622), which the reference hands to its

@@ -20,6 +20,8 @@
 #include "rt_internal.h"
 #include "rt_kernels.hip.h"
 
+// The library's static device scratch (see "static device scratch" below): every device holds its own copy.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
 
 namespace {
 
@@ -534,6 +536,48 @@ uint32_t stack_lds_bytes(const rt_scene *s) {
 
 Shards single_shard(const RenderCtx &c) { return Shards{1u, c.np.capacity, c.sp.capacity, 1u}; }
 
+// ---------------------------------------------------------------- the library's static device scratch
+// rt_render_device_noalloc renders with every pool, counter and tile list in this array instead of hipMalloc'ed memory.
+// Each device the library runs on holds its own copy (at its own address) until the process ends.  The array's name
+// is a host-side stand-in, not a device address: host code only ever uses the pointer hipGetSymbolAddress returned for
+// the device in question (scratch_for_device, called from rt_scene_create with that device current).
+constexpr uint64_t SCRATCH_BYTES = RT_NOALLOC_SCRATCH_BYTES;  // also the extent of `scratch` (file scope, top of this file)
+constexpr uint32_t SCRATCH_MAX_TILES = 4096;
+constexpr uint64_t SCRATCH_CTR_BYTES = (MAX_SHARDS * sizeof(Counters) + 255) & ~uint64_t(255);
+constexpr uint64_t SCRATCH_TILE_BYTES = SCRATCH_MAX_TILES * 2 * sizeof(uint32_t);
+constexpr uint64_t SCRATCH_POOL_BYTES = SCRATCH_BYTES - SCRATCH_CTR_BYTES - SCRATCH_TILE_BYTES;
+
+constexpr int MAX_DEVICES = 64;
+struct FixedCtx {
+    void *ptr = nullptr;  // this device's address of `scratch`
+    RenderCtx ctx;        // carved from it once
+    Counters h_ctr[MAX_SHARDS];
+};
+FixedCtx g_fixed[MAX_DEVICES];
+std::mutex g_fixed_mutex;
+
+// Once per device, with that device current: the device address of `scratch`, and the render context carved from it.
+int scratch_for_device(int device, void **out) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(RT_ERR_UNSUPPORTED, "device index beyond 63");
+    std::lock_guard<std::mutex> lock(g_fixed_mutex);
+    FixedCtx &f = g_fixed[device];
+    if (!f.ptr) {
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(RT_ERR_DEVICE, "hipGetSymbolAddress(scratch) returned a null address");
+        char *base = static_cast<char *>(ptr);
+        RenderCtx &c = f.ctx;
+        c.d_ctr = reinterpret_cast<Counters *>(base);
+        c.d_tiles = reinterpret_cast<uint32_t *>(base + SCRATCH_CTR_BYTES);
+        c.d_tiles_cap = SCRATCH_MAX_TILES;
+        c.can_grow = false;
+        c.h_ctr = f.h_ctr;
+        if (int rc = carve_pools(base + SCRATCH_CTR_BYTES + SCRATCH_TILE_BYTES, SCRATCH_POOL_BYTES, &c.np, &c.sp)) return rc;
+        f.ptr = ptr;
+    }
+    *out = f.ptr;
+    return RT_OK;
+}
 
 // Entry points never unwind across the boundary, and run with the scene's device current (restored on exit).
 struct DeviceScope {
@@ -853,6 +897,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     if ((rc = upload(st, texels, &dev.texels, sc->allocs, bytes))) return rc;
     lap("upload");
     if (timing) std::fprintf(stderr, "rt_scene_create:   of which hipMalloc %.1f ms, staging fill %.1f ms, DMA wait %.1f ms\n", st.ms_alloc, st.ms_fill, st.ms_wait);
+    if ((rc = scratch_for_device(sc->device, &sc->scratch))) return rc;
     *out = sc.release();
     return RT_OK;
 }
@@ -1117,6 +1162,31 @@ int rt_render_aov_device(rt_scene *s, const rt_render_params *params, double *d_
     });
 }
 
+int rt_render_device_noalloc(rt_scene *s, const rt_render_params *params, double *d_rgb_accum, uint64_t *ray_count, void *stream_v) {
+    if (!s || !d_rgb_accum) return fail(RT_ERR_INVALID, "null argument");
+    return guarded_on(s, [&]() -> int {
+        if (!s->scratch) return fail(RT_ERR_DEVICE, "the static scratch of this device was not resolved at rt_scene_create");
+        // the size limit: camera rays of the call (window pixels x samples), and its tile list
+        const rt_render_options &o = s->dev.opts;
+        rt_render_params p{};
+        if (params) p = *params;
+        const uint64_t wx = (p.x1 == 0 && p.y1 == 0) ? o.width : (p.x1 > p.x0 ? p.x1 - p.x0 : 0);
+        const uint64_t wy = (p.x1 == 0 && p.y1 == 0) ? o.height : (p.y1 > p.y0 ? p.y1 - p.y0 : 0);
+        const uint64_t ns = p.s1 == 0 ? o.samples_per_pixel : (p.s1 > p.s0 ? p.s1 - p.s0 : 0);
+        uint64_t rays = wx * wy * ns;
+        if (p.shard_count > 1) rays = rays / p.shard_count + 1;
+        if (rays > RT_NOALLOC_MAX_CAMERA_RAYS)
+            return fail(RT_ERR_NOMEM, "rt_render_device_noalloc: " + std::to_string(rays) + " camera rays in this call, the limit is " +
+                                          std::to_string(static_cast<uint64_t>(RT_NOALLOC_MAX_CAMERA_RAYS)) + " (window pixels x samples); split the window or the sample range");
+        if (p.flags & RT_FLAG_COUNT_WORK) return fail(RT_ERR_INVALID, "rt_render_device_noalloc takes no flags");
+        FixedCtx &f = g_fixed[s->device];
+        if (f.ptr != s->scratch) return fail(RT_ERR_DEVICE, "internal: scratch address mismatch");
+        // the scratch is shared by every scene on this device: its plan cache and expansion estimates belong to the last caller
+        f.ctx.plan_valid = false;
+        f.ctx.est_nodes_per_item = f.ctx.est_shadows_per_item = 0.0;
+        return render_impl(s, f.ctx, params, d_rgb_accum, nullptr, nullptr, ray_count, nullptr, static_cast<hipStream_t>(stream_v));
+    });
+}
 
 int rt_render_aov(rt_scene *s, const rt_render_params *params, double *rgb_accum, double *albedo, double *normal,
                   uint64_t *ray_count, rt_render_stats *stats) {

@@ -16,6 +16,7 @@ EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_set_pool_bytes", "rt_render_device", "rt_tonemap_device",
     "rt_render", "rt_render_aov_device", "rt_render_aov", "rt_query_primary", "rt_trace_rays", "rt_scene_info", "rt_last_error", "rt_version",
     "rt_render_progressive",
+    "rt_render_device_noalloc",
 ]
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64)
@@ -68,6 +69,8 @@ def lib():
         l.rt_render.restype = C.c_int
         l.rt_render_progressive.argtypes = [vp, C.POINTER(_abi.RenderParams), C.c_uint32, u32p, PROGRESS_FN, vp, f64p, u64p]
         l.rt_render_progressive.restype = C.c_int
+        l.rt_render_device_noalloc.argtypes = [vp, C.POINTER(_abi.RenderParams), vp, u64p, vp]
+        l.rt_render_device_noalloc.restype = C.c_int
         l.rt_query_primary.argtypes = [vp, u32p, f64p, f64p]
         l.rt_query_primary.restype = C.c_int
         l.rt_trace_rays.argtypes = [vp, C.c_uint32, f64p, f64p, f64p, C.c_int, u32p, f64p]
@@ -152,6 +155,13 @@ class DeviceScene:
             )
         )
         return int(count.value), stats
+
+    def render_device_noalloc(self, d_accum_ptr, params=None, stream=None):
+        """rt_render_device_noalloc: as render_device, but every pool lives in the library's static device scratch."""
+        params = params or _abi.RenderParams()
+        count = C.c_uint64(0)
+        _check(lib().rt_render_device_noalloc(self._h, C.byref(params), C.c_void_p(d_accum_ptr), C.byref(count), C.c_void_p(stream or 0)))
+        return int(count.value)
 
     def render_progressive(self, n_passes, params=None, on_pass=None, want_accum=False):
         """rt_render_progressive -> (argb[h,w] u32, rgb_sum or None, ray_count).  on_pass(argb_view, passes_done, n_passes, rays)
