@@ -193,57 +193,106 @@ def main():
         dominant = max(ms, key=ms.get)
         kern = "closest" if dominant not in ("closest", "shadow") else dominant
         k_rays = work.closest_rays if kern == "closest" else work.shadow_rays
-        k_bytes = bytes_c if kern == "closest" else bytes_s
+        k_bytes = bytes_c if kern == "closest" else bytes_s          # SURVEY 8(d) incl. the geometry term
+        k_stream = 224.0 if kern == "closest" else 136.0             # SURVEY 8(d) wavefront records only: what MUST cross HBM
         k_ms = ms[kern]
-        achieved = k_rays * k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        n_launch = max(1.0, launches[kern])
+        gbs = lambda nbytes, msec: nbytes / (msec * 1e-3) / 1e9 if msec > 0 else 0.0
+        stream_gbs = gbs(k_rays * k_stream, k_ms)
+        incl_cache_gbs = gbs(k_rays * k_bytes, k_ms)
+        # HBM traffic (PMC passes cannot run inside this process: they are taken by tools/profile_all.sh on the same
+        # workload and tree, committed under profiles/, and replayed here -- `source` says which file)
         default_workload = os.path.basename(args.scene) == "scene.json" and not args.spp and not args.size
-        if default_workload and os.path.exists(pmc_path):  # the PMC passes were taken on this workload only
+        pmc_t, pmc_v = {}, {}
+        if default_workload:
             try:
-                traffic = json.load(open(pmc_path)).get("k_trace_" + kern, {}).get("hbm_bytes_per_launch")
+                pmc_t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                pmc_v = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
             except Exception:
-                traffic = None
+                pmc_t, pmc_v = {}, {}
+        src_t = f"profiles/pmc_traffic.json ({pmc_t.get('_tree', 'r01g')}), replayed" if pmc_t else None
+        src_v = f"profiles/pmc_valu.json ({pmc_v.get('_tree', 'r01g')}), replayed" if pmc_v else None
+        traffic = pmc_t.get("k_trace_" + kern, {}).get("hbm_bytes_per_launch")
+        measured_gbs = gbs(traffic * n_launch, k_ms) if traffic else None
         valu = None
-        valu_path = os.path.join(ROOT, "profiles", "pmc_valu.json")
-        if default_workload and os.path.exists(valu_path):  # SQ_* PMC passes of the same workload (tools/profile_all.sh)
-            try:
-                v = json.load(open(valu_path)).get("k_trace_" + kern, {})
-                valu = {k: v[k] for k in ("valu_busy", "lane_use", "fp64_tflops", "fp64_frac_of_peak", "wait_share") if k in v} or None
-            except Exception:
-                valu = None
+        if pmc_v.get("k_trace_" + kern):
+            v = pmc_v["k_trace_" + kern]
+            valu = {k: v[k] for k in ("valu_busy", "lane_use", "fp64_tflops", "fp64_frac_of_peak", "wait_share") if k in v}
+            valu["source"] = src_v
+        # whole frame: HBM bytes of every kernel of one step (PMC, replayed) against the step's wall time
+        frame_bytes = None
+        if pmc_t:
+            per_step = {"k_trace_closest": launches["closest"], "k_trace_shadow": launches["shadow"]}
+            tot = 0.0
+            for k, rec in pmc_t.items():
+                if not isinstance(rec, dict) or "hbm_bytes_per_launch" not in rec:
+                    continue
+                tot += rec["hbm_bytes_per_launch"] * per_step.get(k, rec.get("launches", 0) / max(1, pmc_t.get("_frames", 2)))
+            frame_bytes = int(tot)
+        step_ms = 1e3 * elapsed / max(1, args.steps)
+        bound = "valu_issue" if (valu and valu.get("valu_busy", 0.0) >= 0.5 and (measured_gbs or 0.0) < 0.5 * HBM_PEAK_GBS) else "hbm"
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_trace_" + kern, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "launches_per_step": launches[kern], "avg_launch_ms": round(k_ms / max(1.0, launches[kern]), 4),
-            "algorithmic_bytes_per_ray": round(k_bytes, 1), "rays_per_step": int(k_rays),
+            # `achieved` / `frac`: the kernel's ALGORITHMIC HBM bytes -- SURVEY 8(d)'s wavefront records, 224 B per closest-hit
+            # ray (136 B per shadow ray), which every design must move once -- over its HIP-event time.  The geometry term of
+            # 8(d) (64 B per node visit, 72 / 104 B per primitive test) is cache traffic for scenes that fit L2 / LDS and is
+            # reported apart (`algorithmic_incl_cache_gbs`: not a bound, it exceeds the HBM peak on L2-resident scenes).
+            "bound": bound, "kernel": "k_trace_" + kern, "achieved": round(stream_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(stream_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src_t,
+            "frac_hbm_stream": round(stream_gbs / HBM_PEAK_GBS, 4),
+            "frac_hbm_measured": round(measured_gbs / HBM_PEAK_GBS, 4) if measured_gbs else None,
+            "algorithmic_incl_cache_gbs": round(incl_cache_gbs, 2),
+            "launches_per_step": launches[kern], "avg_launch_ms": round(k_ms / n_launch, 4),
+            "stream_bytes_per_ray": k_stream, "algorithmic_bytes_per_ray_incl_cache": round(k_bytes, 1), "rays_per_step": int(k_rays),
             "nodes_per_ray": round(nodes_c if kern == "closest" else nodes_s, 2),
             "prims_per_ray": round(prims_c if kern == "closest" else prims_s, 2),
             "kernel_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
             "dominant_class": dominant,
-            "valu": valu,  # co-limit: VALU issue occupancy / lane use / FP64 rate of the same kernel, from profiles/pmc_valu.json
-            "pipeline_gbs": round((work.closest_rays * bytes_c + work.shadow_rays * bytes_s) / (elapsed / max(1, args.steps)) / 1e9, 2),
+            "valu": valu,  # co-limit: VALU issue occupancy / lane use / FP64 rate of the same kernel
+            "frame": {
+                "stream_bytes_per_step": int(work.closest_rays * 224.0 + work.shadow_rays * 136.0),
+                "frac_hbm_stream": round(gbs(work.closest_rays * 224.0 + work.shadow_rays * 136.0, step_ms) / HBM_PEAK_GBS, 4),
+                "hbm_bytes_per_step": frame_bytes, "hbm_bytes_source": src_t if frame_bytes else None,
+                "frac_hbm_measured": round(gbs(frame_bytes, step_ms) / HBM_PEAK_GBS, 4) if frame_bytes else None,
+            },
         }
-        # ---- CPU baseline: the reference's algorithm (kd-tree order) on the host cores, bounded sample
+        # ---- CPU baseline: the reference's algorithm (kd-tree order) on the host cores, bounded samples of the same frame
         if not args.no_cpu_baseline:
             from oracle import binding as ob
 
-            cores = min(16, os.cpu_count() or 1)
+            # threads: the CPU share this process may use (a one-GPU box grants 16 of the machine's CPUs: OMP_NUM_THREADS)
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except Exception:
+                avail = os.cpu_count() or 1
+            share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+            cores = max(1, min(avail, share) if share > 0 else avail)
+            model = "unknown"
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        model = line.split(":", 1)[1].strip()
+                        break
+            except Exception:
+                pass
             cpu = ob.OracleScene(scene.desc)
-            # bounded sample: the whole frame when that is ~10 s of CPU work (scene.json: ~3-4 s on 16 host
-            # cores), otherwise a centred band of rows of the same frame sized for ~10-30 s of CPU work
             rays_frame = rays // max(1, args.steps)
-            rows = max(1, min(h, int(h * min(1.0, 10.0 * 15e6 / max(1, rays_frame)))))
-            y0 = (h - rows) // 2
-            y1 = y0 + rows
-            p = _abi.RenderParams(seed=0, x0=0, y0=y0, x1=w, y1=y1)
-            t0 = time.perf_counter()
-            _, _, n_cpu = cpu.render(p, mode=ob.MODE_KD, threads=cores, want_rgba=False)
-            dt = time.perf_counter() - t0
+
+            def cpu_run(threads, budget_rays):  # a centred band of rows of the same frame, sized to ~budget_rays
+                rows = max(1, min(h, int(h * min(1.0, budget_rays / max(1, rays_frame)))))
+                y0 = (h - rows) // 2
+                p = _abi.RenderParams(seed=0, x0=0, y0=y0, x1=w, y1=y0 + rows)
+                t0 = time.perf_counter()
+                _, _, n_cpu = cpu.render(p, mode=ob.MODE_KD, threads=threads, want_rgba=False)
+                dt = time.perf_counter() - t0
+                return n_cpu / dt / 1e6, f"rows {y0}..{y0 + rows} of the same frame ({n_cpu} rays, {dt:.1f} s)"
+
+            v_all, s_all = cpu_run(cores, 10.0 * 3.0e6 * cores)  # ~10 s at ~3 Mrays/s per thread
+            v_one, s_one = cpu_run(1, 10.0 * 3.0e6)
             out["cpu_baseline"] = {
-                "value": round(n_cpu / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                "sample": f"rows {y0}..{y1} of the same frame ({n_cpu} rays, {dt:.1f} s), oracle MODE_KD = C++ port of the reference "
-                          f"(SAH kd-tree, f64, std::thread over rows)",
+                "value": round(v_all, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": s_all + ", oracle MODE_KD = C++ port of the reference (SAH kd-tree, f64, std::thread over rows)",
+                "one_thread": {"value": round(v_one, 3), "cores": 1, "sample": s_one},
+                "host": {"cpu_model": model, "nproc": os.cpu_count(), "usable_threads": cores},
             }
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -163,11 +163,16 @@ pub struct rt_scene {
     _private: [u8; 0],
 }
 
+/// `int (*rt_progress_fn)(void *user, uint32_t passes_done, uint32_t n_passes, uint64_t rays_so_far)`; NULL allowed.
+pub type rt_progress_fn = Option<unsafe extern "C" fn(user: *mut c_void, passes_done: u32, n_passes: u32, rays_so_far: u64) -> c_int>;
+
 extern "C" {
     pub fn rt_scene_create(desc: *const rt_scene_desc, out: *mut *mut rt_scene) -> c_int;
     pub fn rt_scene_destroy(scene: *mut rt_scene);
     pub fn rt_scene_set_pool_bytes(scene: *mut rt_scene, bytes: u64) -> c_int;
     pub fn rt_render_device(scene: *mut rt_scene, params: *const rt_render_params, d_rgb_accum: *mut f64, ray_count: *mut u64, stats: *mut rt_render_stats, stream: *mut c_void) -> c_int;
+    pub fn rt_render_device_noalloc(scene: *mut rt_scene, params: *const rt_render_params, d_rgb_accum: *mut f64, ray_count: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn rt_render_progressive(scene: *mut rt_scene, params: *const rt_render_params, n_passes: u32, argb: *mut u32, on_pass: rt_progress_fn, user: *mut c_void, rgb_accum: *mut f64, ray_count: *mut u64) -> c_int;
     pub fn rt_render_aov_device(scene: *mut rt_scene, params: *const rt_render_params, d_rgb_accum: *mut f64, d_albedo_accum: *mut f64, d_normal: *mut f64, ray_count: *mut u64, stats: *mut rt_render_stats, stream: *mut c_void) -> c_int;
     pub fn rt_render_aov(scene: *mut rt_scene, params: *const rt_render_params, rgb_accum: *mut f64, albedo: *mut f64, normal: *mut f64, ray_count: *mut u64, stats: *mut rt_render_stats) -> c_int;
     pub fn rt_tonemap_device(scene: *mut rt_scene, d_rgb_accum: *const f64, d_rgba8: *mut u8, stream: *mut c_void) -> c_int;

@@ -1,6 +1,9 @@
-// `raytrace <scene.json> -o out.png [--no-progress]` -- the reference CLI's
-// flags and output lines (src/main.rs:9-78) on top of the C ABI.  The window
-// preview (no -o) is out of scope: -o is required here.
+// `raytrace <scene.json> -o out.png [--no-progress] [--passes N]` -- the reference
+// CLI's flags and output lines (src/main.rs:9-78) on top of the C ABI.  The window
+// preview (no -o) is out of scope: -o is required here; --passes N renders the frame
+// progressively (rt_render_progressive, the counterpart of raytrace_to_buffer's
+// progressively filled buffer) and reports pixels done + rays after every pass, which
+// is what the reference's progress bar shows (raytracing_scene.rs:624-643).
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -17,6 +20,8 @@ static double seconds_since(std::chrono::steady_clock::time_point t0) {
 int main(int argc, char **argv) {
     const char *scene_path = nullptr, *output = nullptr;
     unsigned long long seed = 0;
+    unsigned passes = 0;
+    bool progress = true;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "-o") || !std::strcmp(argv[i], "--output")) {
             if (++i >= argc) {
@@ -25,7 +30,10 @@ int main(int argc, char **argv) {
             }
             output = argv[i];
         } else if (!std::strcmp(argv[i], "--no-progress")) {
-            // accepted for compatibility: a frame renders in well under a second
+            progress = false;
+        } else if (!std::strcmp(argv[i], "--passes")) {
+            if (++i >= argc) return 2;
+            passes = static_cast<unsigned>(std::strtoul(argv[i], nullptr, 10));
         } else if (!std::strcmp(argv[i], "--seed")) {
             if (++i >= argc) return 2;
             seed = std::strtoull(argv[i], nullptr, 10);
@@ -34,6 +42,7 @@ int main(int argc, char **argv) {
                         "ARGS:\n    <scene>    input scene as a json file\n\nOPTIONS:\n"
                         "    -o, --output <output>    Output rendered image to file\n"
                         "        --no-progress        Hide progress bar\n"
+                        "        --passes <n>         Render progressively in n passes\n"
                         "        --seed <n>           Sample-stream seed (default 0)\n");
             return 0;
         } else if (!scene_path) {
@@ -79,7 +88,32 @@ int main(int argc, char **argv) {
     rt_render_stats stats{};
     uint64_t rays = 0;
     t0 = std::chrono::steady_clock::now();
-    if (rt_render(scene, &params, nullptr, rgba.data(), &rays, &stats) != RT_OK) {
+    int rc;
+    if (passes > 1) {
+        const size_t npx = static_cast<size_t>(desc->opts.width) * desc->opts.height;
+        std::vector<uint32_t> argb(npx);
+        struct Ctx {
+            bool progress;
+            size_t npx;
+        } ctx{progress, npx};
+        auto on_pass = [](void *user, uint32_t done, uint32_t total, uint64_t rays_so_far) -> int {
+            const Ctx *c = static_cast<const Ctx *>(user);
+            if (c->progress)
+                std::printf("pass %u/%u: %zu/%zu pixels, %llu rays\n", done, total, c->npx * done / total, c->npx,
+                            static_cast<unsigned long long>(rays_so_far));
+            return 0;
+        };
+        rc = rt_render_progressive(scene, &params, passes, argb.data(), on_pass, &ctx, nullptr, &rays);
+        for (size_t i = 0; i < npx; ++i) {  // ARGB words -> RGBA bytes
+            rgba[4 * i] = static_cast<uint8_t>(argb[i] >> 16);
+            rgba[4 * i + 1] = static_cast<uint8_t>(argb[i] >> 8);
+            rgba[4 * i + 2] = static_cast<uint8_t>(argb[i]);
+            rgba[4 * i + 3] = static_cast<uint8_t>(argb[i] >> 24);
+        }
+    } else {
+        rc = rt_render(scene, &params, nullptr, rgba.data(), &rays, &stats);
+    }
+    if (rc != RT_OK) {
         std::fprintf(stderr, "render failed: %s\n", rt_last_error());
         return 1;
     }

@@ -373,6 +373,44 @@ def test_progressive_passes_end_in_the_one_shot_frame(rt):
     assert 0 < n_part < n1 and (part == 0).any() and np.array_equal(part[part != 0], want[part != 0])
 
 
+def test_raytrace_cli_and_render_scenes_report(rt, tmp_path):
+    """The `raytrace` binary (src/main.rs:9-78) and tools/render_scenes.py (src/render_scenes.rs:43-77): the PNGs they write
+    hold the pixels rt_render returns, and their report lines have the reference's form."""
+    import re
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    from conftest import ROOT
+
+    device, _, abi = rt
+    s = load_scene("test")
+    gpu = device.DeviceScene(s.desc)
+    exe = os.path.join(ROOT, "raytracer_amd", "raytrace")
+    _, want, n, _ = gpu.render(abi.RenderParams(seed=0))
+    for extra in ([], ["--passes", "4"], ["--passes", "3", "--no-progress"]):
+        out = str(tmp_path / "cli.png")
+        r = subprocess.run([exe, os.path.join(ROOT, "scenes", "test.json"), "-o", out] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert np.array_equal(np.array(Image.open(out).convert("RGBA")), want)
+        assert re.search(r"Took [0-9.]+s to load assets\.", r.stdout) and re.search(r"pre-process scene and construct bounding boxes for 9 primitives", r.stdout)
+        assert re.search(r"Took [0-9.]+s to render the scene\.", r.stdout) and f"{n} rays" in r.stdout and "Output written to" in r.stdout
+        assert ("pass 4/4: 640000/640000 pixels" in r.stdout) == (extra == ["--passes", "4"])
+    r = subprocess.run([exe, os.path.join(ROOT, "scenes", "nope.json"), "-o", str(tmp_path / "x.png")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "failed to parse scene" in r.stderr
+    assert subprocess.run([exe], capture_output=True, text=True, timeout=60).returncode == 2
+    # render-scenes: report lines of src/render_scenes.rs:55-69 and the last iteration's frame (seed = iteration index)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "render_scenes.py"), str(tmp_path), "--scenes", "test", "--iterations", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert re.search(r"Raytracing .*scenes/test\.json \(9 primitives\)\.\.\.", r.stdout)
+    assert len(re.findall(r"Iteration \d: rendered in [0-9.]+ms \(\d+ rays\)", r.stdout)) == 2
+    assert re.search(r"Final render: 800 x 800 pixels, 4 spp, 9 primitives, \d+ rays, [0-9.]+ms", r.stdout)
+    _, want1, _, _ = gpu.render(abi.RenderParams(seed=1))
+    assert np.array_equal(np.array(Image.open(str(tmp_path / "test.png")).convert("RGBA")), want1)
+
+
 def test_cornell_box_full_size_against_live_oracle(rt):
     """BASELINE config 2 at its full size: cornell_box.json 800x800 at 16 spp (10.24 M camera rays) on the HIP path against
     the live oracle.  The box's light and ceiling are coplanar (scenes/models/cornell_box/light.obj, ceiling.obj, quirk
