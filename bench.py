@@ -65,9 +65,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # Launched plainly with --gpus N > 1: ONE process drives N GPUs through the library (rt_render_multi_device: a host
+    # thread and a stream per device, tiles sent to device 0 by peer copies).  Under torch.distributed.run (what the
+    # driver does): one process per GPU, RCCL for the exchange.
+    single_process_multi = world == 1 and args.gpus > 1
+    if world != args.gpus and not single_process_multi:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -109,6 +111,14 @@ def main():
         scene.set_option("height", max(1, round(args.size * aspect)))
     w, h, spp = int(scene.opts.width), int(scene.opts.height), int(scene.opts.samples_per_pixel)
     gpu = device.DeviceScene(scene.desc, pool_bytes=int(args.pool_gib * (1 << 30)) or None)
+    replicas = [gpu]
+    if single_process_multi:
+        if not rehearse and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} visible")
+        for i in range(1, args.gpus):  # a replica of the scene per device (all on cuda:0 in a rehearsal)
+            torch.cuda.set_device(0 if rehearse else i)
+            replicas.append(device.DeviceScene(scene.desc, pool_bytes=int(args.pool_gib * (1 << 30)) or None))
+        torch.cuda.set_device(local_rank)
     accum = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
     rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -124,7 +134,16 @@ def main():
             stats_log.append(st)
         return n
 
+    def step_multi():
+        accum.zero_()
+        torch.cuda.current_stream().synchronize()
+        n, _ = device.render_multi_device(replicas, accum.data_ptr(), _abi.RenderParams(seed=0, tile_size=args.tile), stream=stream)
+        gpu.tonemap_device(accum.data_ptr(), rgba.data_ptr(), stream=stream)
+        return n
+
     def step(flags=0):
+        if single_process_multi:
+            return step_multi()
         accum.zero_()
         # frame exchange inside (gather of own tiles / reduce of frames); the ray counters are summed once per run
         _, local = distributed.render_frame(lambda p, a: render_local(p, a, flags), accum, rank, world, spp, seed=0,
@@ -163,17 +182,18 @@ def main():
         value = rays / elapsed / 1e6
         out = {
             "metric": f"Mrays/sec (whole node) on {os.path.basename(args.scene)} {w}x{h} {spp}spp", "value": round(value, 3), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 4),
+            "n_gpus": args.gpus if single_process_multi else world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"{os.path.basename(args.scene)} {w}x{h} {spp}spp, {scene.n_prims} primitives, "
                             f"{rays // max(1, args.steps)} rays/frame ({config_tag}); scene resident in HBM, frame reduced to rank 0",
-                "parallelism": f"tiles{world}" + (f"xsamples{args.sample_shards}" if args.sample_shards > 1 else ""),
+                "parallelism": (f"tiles{args.gpus} (one process, rt_render_multi_device)" if single_process_multi else
+                                f"tiles{world}" + (f"xsamples{args.sample_shards}" if args.sample_shards > 1 else "")),
                 "tile": args.tile, "rays_per_step": rays // max(1, args.steps),
             },
         }
 
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not single_process_multi:
         # ---- roofline of the dominant kernel class (one extra untimed frame counts BVH work)
         stats_log.clear()
         step(_abi.RT_FLAG_COUNT_WORK)

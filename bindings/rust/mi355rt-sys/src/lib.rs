@@ -173,6 +173,8 @@ extern "C" {
     pub fn rt_render_device(scene: *mut rt_scene, params: *const rt_render_params, d_rgb_accum: *mut f64, ray_count: *mut u64, stats: *mut rt_render_stats, stream: *mut c_void) -> c_int;
     pub fn rt_render_device_noalloc(scene: *mut rt_scene, params: *const rt_render_params, d_rgb_accum: *mut f64, ray_count: *mut u64, stream: *mut c_void) -> c_int;
     pub fn rt_render_progressive(scene: *mut rt_scene, params: *const rt_render_params, n_passes: u32, argb: *mut u32, on_pass: rt_progress_fn, user: *mut c_void, rgb_accum: *mut f64, ray_count: *mut u64) -> c_int;
+    pub fn rt_render_multi_device(scenes: *const *mut rt_scene, n_scenes: u32, params: *const rt_render_params, d_rgb_accum: *mut f64, ray_count: *mut u64, stats: *mut rt_render_stats, stream: *mut c_void) -> c_int;
+    pub fn rt_render_multi(scenes: *const *mut rt_scene, n_scenes: u32, params: *const rt_render_params, rgb_accum: *mut f64, rgba8: *mut u8, ray_count: *mut u64, stats: *mut rt_render_stats) -> c_int;
     pub fn rt_render_aov_device(scene: *mut rt_scene, params: *const rt_render_params, d_rgb_accum: *mut f64, d_albedo_accum: *mut f64, d_normal: *mut f64, ray_count: *mut u64, stats: *mut rt_render_stats, stream: *mut c_void) -> c_int;
     pub fn rt_render_aov(scene: *mut rt_scene, params: *const rt_render_params, rgb_accum: *mut f64, albedo: *mut f64, normal: *mut f64, ray_count: *mut u64, stats: *mut rt_render_stats) -> c_int;
     pub fn rt_tonemap_device(scene: *mut rt_scene, d_rgb_accum: *const f64, d_rgba8: *mut u8, stream: *mut c_void) -> c_int;

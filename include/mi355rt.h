@@ -249,6 +249,22 @@ int rt_tonemap_device(rt_scene *scene, const double *d_rgb_accum, uint8_t *d_rgb
 int rt_render(rt_scene *scene, const rt_render_params *params, double *rgb_accum, uint8_t *rgba8,
               uint64_t *ray_count, rt_render_stats *stats);
 
+/* One host process, several GPUs (or several streams of one): the multi-device form of the pixel loop, SURVEY 8(b)/(e).
+ * The reference's only parallelism is rayon's par_iter over the pixels of a frame (src/render/raytracing_scene.rs:734-744);
+ * here `scenes[0..n_scenes)` are replicas of ONE scene (rt_scene_create called n_scenes times with the same descriptor,
+ * each with the device it shall live on current), and the frame described by `params` (window, sample range, seed;
+ * shard_index / shard_count must be 0 -- the library deals the tiles, tile_size 0 -> 8) is rendered by all of them at
+ * once: scene i takes the i-th of n_scenes Morton-interleaved tile shards on a host thread of its own, the shards'
+ * tiles travel to scenes[0]'s device (hipMemcpyPeerAsync, direct over xGMI where peer access exists; 1/n_scenes of
+ * the frame per link) and are added into d_rgb_accum there.  Every pixel has exactly one contributor, so the result is
+ * bit-identical to one rt_render_device call.  d_rgb_accum: DEVICE pointer on scenes[0]'s device (+= semantics);
+ * stream: a hipStream_t of that device (NULL = default); stats: NULL or n_scenes entries (one per scene).  Blocking. */
+int rt_render_multi_device(rt_scene *const *scenes, uint32_t n_scenes, const rt_render_params *params, double *d_rgb_accum,
+                           uint64_t *ray_count, rt_render_stats *stats, void *stream);
+/* Host-pointer convenience, as rt_render: zero-initialised accumulation on scenes[0]'s device, render, tonemap, copy back. */
+int rt_render_multi(rt_scene *const *scenes, uint32_t n_scenes, const rt_render_params *params, double *rgb_accum, uint8_t *rgba8,
+                    uint64_t *ray_count, rt_render_stats *stats);
+
 /* Replaces raytrace_to_buffer's progressively filled window buffer (src/render/raytracing_scene.rs:778-875): the
  * frame is rendered in `n_passes` passes; pass k completes (all samples) the 8x8 tiles dealt to it in a scattered order
  * (the reference visits the pixels in a shuffled order, :824-825) and writes `utils::to_argb_u32` (src/utils/mod.rs:14-19)

@@ -270,17 +270,47 @@ struct rt_scene {
     void *pool_mem = nullptr;
     uint64_t pool_mem_bytes = 0;
     RenderCtx ctx;
+    // rt_render_multi*: what a scene needs to take part as one shard of a frame (allocated at its first such call)
+    struct Multi {
+        double *frame = nullptr;    // w*h*3 on the scene's device: the shard's pixels in place
+        double *packed = nullptr;   // the shard's tiles, tile-major: what travels to the root device
+        uint32_t *tiles = nullptr;  // the shard's tile list (image order)
+        uint64_t packed_cap = 0;    // doubles
+        uint32_t tiles_cap = 0;     // tiles
+        hipStream_t stream = nullptr;
+        // on the ROOT scene's device (root_device): where the packed tiles arrive, and the tile list again
+        int root_device = -1;
+        double *inbox = nullptr;
+        uint32_t *tiles_root = nullptr;
+        uint64_t inbox_cap = 0;
+        uint32_t tiles_root_cap = 0;
+        bool peer_enabled = false;
+        rt_render_params key{};     // the (params, shard) the tile lists were made for
+        uint32_t key_index = 0, key_count = 0;
+        uint32_t n_tiles = 0, tile_w = 0, tile_h = 0;
+        bool key_valid = false;
+    } multi;
     void *scratch = nullptr;  // this device's copy of the library's static scratch (hipGetSymbolAddress at create)
 
     ~rt_scene() {
         int prev = -1;
-        const bool switched = hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) hipSetDevice(device);
         for (void *p : allocs) hipFree(p);
         if (pool_mem) hipFree(pool_mem);
         if (ctx.d_ctr) hipFree(ctx.d_ctr);
         if (ctx.h_ctr) hipHostFree(ctx.h_ctr);
         if (ctx.d_tiles) hipFree(ctx.d_tiles);
-        if (switched) hipSetDevice(prev);
+        if (multi.frame) hipFree(multi.frame);
+        if (multi.packed) hipFree(multi.packed);
+        if (multi.tiles) hipFree(multi.tiles);
+        if (multi.stream) hipStreamDestroy(multi.stream);
+        if (multi.inbox || multi.tiles_root) {
+            if (multi.root_device != device) hipSetDevice(multi.root_device);
+            if (multi.inbox) hipFree(multi.inbox);
+            if (multi.tiles_root) hipFree(multi.tiles_root);
+        }
+        if (prev >= 0) hipSetDevice(prev);
     }
 };
 
@@ -1364,6 +1394,188 @@ int rt_trace_rays(rt_scene *s, uint32_t n, const double *origin, const double *d
         if (t && !shadow)
             for (uint32_t i = 0; i < n; ++i)
                 if (prim_id[i] == RT_NO_HIT) t[i] = 0.0;
+        return RT_OK;
+    });
+}
+
+}  // extern "C"
+
+namespace {
+
+// (re)allocate a device buffer of at least `need` elements on the CURRENT device
+template <typename T, typename N>
+int grow(T **buf, N *cap, uint64_t need) {
+    if (*buf && *cap >= need) return RT_OK;
+    if (*buf) hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(buf), need * sizeof(T)));
+    *cap = static_cast<N>(need);
+    return RT_OK;
+}
+
+// One shard of a multi-device frame, on its own host thread: render the tiles dealt to scene `index` of `count` into
+// the scene's frame buffer, pack them, send them to the root device.  The root shard (index 0) renders straight into
+// the caller's buffer.  Returns with the shard's stream drained.
+int multi_shard(rt_scene *s, rt_scene *root, uint32_t index, uint32_t count, const rt_render_params &base, double *d_root_accum,
+                hipStream_t root_stream, uint64_t *rays, rt_render_stats *stats) {
+    DeviceScope scope;
+    if (int rc = scope.enter(s->device)) return rc;
+    rt_scene::Multi &m = s->multi;
+    const rt_render_options &o = s->dev.opts;
+    rt_render_params p = base;
+    p.shard_index = index;
+    p.shard_count = count;
+    if (!p.tile_size) p.tile_size = 8;  // one 64-pixel granule: the finest deal, the best balance
+    if (int rc = ensure_pools(s)) return rc;
+    if (index == 0) return render_impl(s, s->ctx, &p, d_root_accum, nullptr, nullptr, rays, stats, root_stream);
+
+    if (!m.stream) HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+    // tile lists of this shard, here and on the root device (image order: rt_shard_tiles' order)
+    rt_render_params key = p;
+    key.seed = 0;
+    key.flags = 0;
+    key.s0 = key.s1 = 0;
+    const uint64_t n3 = static_cast<uint64_t>(o.width) * o.height * 3;
+    if (!m.frame) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m.frame), n3 * sizeof(double)));
+    if (!m.key_valid || std::memcmp(&key, &m.key, sizeof(key)) != 0 || m.root_device != root->device) {
+        m.key_valid = false;
+        std::vector<uint32_t> tiles;
+        WorkList wl{};
+        if (int rc = plan_tiles(o, &p, &tiles, &wl)) return rc;
+        m.n_tiles = wl.n_tiles;
+        m.tile_w = wl.tile_w;
+        m.tile_h = wl.tile_h;
+        const uint64_t packed_need = std::max<uint64_t>(1, static_cast<uint64_t>(wl.n_tiles) * wl.tile_w * wl.tile_h * 3);
+        if (int rc = grow(&m.tiles, &m.tiles_cap, std::max<uint32_t>(1u, wl.n_tiles) * 2ull)) return rc;
+        if (int rc = grow(&m.packed, &m.packed_cap, packed_need)) return rc;
+        if (wl.n_tiles) HIP_TRY(hipMemcpy(m.tiles, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        {   // the root device's side
+            if (m.root_device >= 0 && m.root_device != root->device && (m.inbox || m.tiles_root)) {  // the root moved: start over there
+                DeviceScope old;
+                if (int rc = old.enter(m.root_device)) return rc;
+                if (m.inbox) hipFree(m.inbox);
+                if (m.tiles_root) hipFree(m.tiles_root);
+                m.inbox = nullptr;
+                m.tiles_root = nullptr;
+                m.inbox_cap = 0;
+                m.tiles_root_cap = 0;
+                m.peer_enabled = false;
+            }
+            DeviceScope on_root;
+            if (int rc = on_root.enter(root->device)) return rc;
+            m.root_device = root->device;
+            if (int rc = grow(&m.tiles_root, &m.tiles_root_cap, std::max<uint32_t>(1u, wl.n_tiles) * 2ull)) return rc;
+            if (int rc = grow(&m.inbox, &m.inbox_cap, packed_need)) return rc;
+            if (wl.n_tiles) HIP_TRY(hipMemcpy(m.tiles_root, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        if (!m.peer_enabled && root->device != s->device) {  // direct xGMI copies; without it the copy is staged through the host
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, s->device, root->device) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+            (void)hipGetLastError();
+            m.peer_enabled = true;
+        }
+        m.key = key;
+        m.key_valid = true;
+    }
+    HIP_TRY(hipMemsetAsync(m.frame, 0, n3 * sizeof(double), m.stream));
+    if (int rc = render_impl(s, s->ctx, &p, m.frame, nullptr, nullptr, rays, stats, m.stream)) return rc;
+    if (m.n_tiles) {
+        const uint64_t total = static_cast<uint64_t>(m.n_tiles) * m.tile_w * m.tile_h * 3;
+        hipLaunchKernelGGL(k_pack_tiles, dim3(grid_1d(total, 4096)), dim3(BLOCK), 0, m.stream, m.tiles, m.n_tiles, m.tile_w, m.tile_h, o.width, o.height,
+                           m.frame, m.packed);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyPeerAsync(m.inbox, root->device, m.packed, s->device, total * sizeof(double), m.stream));
+    }
+    HIP_TRY(hipStreamSynchronize(m.stream));
+    return RT_OK;
+}
+
+int render_multi_impl(rt_scene *const *scenes, uint32_t n, const rt_render_params *params, double *d_rgb_accum, uint64_t *ray_count,
+                      rt_render_stats *stats, hipStream_t stream) {
+    if (!scenes || n == 0 || !d_rgb_accum) return fail(RT_ERR_INVALID, "null argument");
+    if (n > 64) return fail(RT_ERR_UNSUPPORTED, "more than 64 scenes in one rt_render_multi call");
+    rt_render_params base{};
+    if (params) base = *params;
+    if (base.shard_count > 1) return fail(RT_ERR_INVALID, "rt_render_multi deals the tiles itself: shard_count must be 0 or 1");
+    rt_scene *root = scenes[0];
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!scenes[i]) return fail(RT_ERR_INVALID, "null scene");
+        for (uint32_t j = 0; j < i; ++j)
+            if (scenes[j] == scenes[i]) return fail(RT_ERR_INVALID, "the same scene handle twice in one rt_render_multi call");
+        const rt_render_options &a = scenes[i]->dev.opts, &b = root->dev.opts;
+        if (a.width != b.width || a.height != b.height || a.samples_per_pixel != b.samples_per_pixel || a.max_depth != b.max_depth ||
+            scenes[i]->dev.n_prims != root->dev.n_prims)
+            return fail(RT_ERR_INVALID, "rt_render_multi: the scenes are not replicas of one scene (options or primitive counts differ)");
+    }
+    if (n == 1) {
+        DeviceScope scope;
+        if (int rc = scope.enter(root->device)) return rc;
+        if (int rc = ensure_pools(root)) return rc;
+        return render_impl(root, root->ctx, &base, d_rgb_accum, nullptr, nullptr, ray_count, stats, stream);
+    }
+    // one host thread per scene: each drives its own device (or its own stream of a shared device)
+    std::vector<int> rcs(n, RT_OK);
+    std::vector<std::string> errs(n);
+    std::vector<uint64_t> rays(n, 0);
+    std::vector<std::thread> pool;
+    pool.reserve(n);
+    for (uint32_t i = 0; i < n; ++i)
+        pool.emplace_back([&, i] {
+            rcs[i] = guarded([&]() -> int { return multi_shard(scenes[i], root, i, n, base, d_rgb_accum, stream, &rays[i], stats ? stats + i : nullptr); });
+            if (rcs[i]) errs[i] = g_error;
+        });
+    for (auto &t : pool) t.join();
+    for (uint32_t i = 0; i < n; ++i)
+        if (rcs[i]) return fail(rcs[i], "rt_render_multi, scene " + std::to_string(i) + ": " + errs[i]);
+    // exchange step, root side: every other shard's tiles are in its inbox on this device
+    DeviceScope scope;
+    if (int rc = scope.enter(root->device)) return rc;
+    const rt_render_options &o = root->dev.opts;
+    for (uint32_t i = 1; i < n; ++i) {
+        const rt_scene::Multi &m = scenes[i]->multi;
+        if (!m.n_tiles) continue;
+        const uint64_t total = static_cast<uint64_t>(m.n_tiles) * m.tile_w * m.tile_h * 3;
+        hipLaunchKernelGGL(k_unpack_add_tiles, dim3(grid_1d(total, 4096)), dim3(BLOCK), 0, stream, m.tiles_root, m.n_tiles, m.tile_w, m.tile_h, o.width,
+                           o.height, m.inbox, d_rgb_accum);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));  // the inboxes are free for the next call
+    if (ray_count)
+        for (uint32_t i = 0; i < n; ++i) *ray_count += rays[i];
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_render_multi_device(rt_scene *const *scenes, uint32_t n_scenes, const rt_render_params *params, double *d_rgb_accum,
+                           uint64_t *ray_count, rt_render_stats *stats, void *stream) {
+    return guarded([&]() -> int { return render_multi_impl(scenes, n_scenes, params, d_rgb_accum, ray_count, stats, static_cast<hipStream_t>(stream)); });
+}
+
+int rt_render_multi(rt_scene *const *scenes, uint32_t n_scenes, const rt_render_params *params, double *rgb_accum, uint8_t *rgba8,
+                    uint64_t *ray_count, rt_render_stats *stats) {
+    if (!scenes || n_scenes == 0 || !scenes[0]) return fail(RT_ERR_INVALID, "null argument");
+    rt_scene *root = scenes[0];
+    return guarded_on(root, [&]() -> int {
+        const uint64_t n = static_cast<uint64_t>(root->dev.opts.width) * root->dev.opts.height;
+        DevBuf acc, img;
+        if (int rc = acc.alloc(n * 3 * sizeof(double))) return rc;
+        HIP_TRY(hipMemset(acc.p, 0, n * 3 * sizeof(double)));
+        if (int rc = render_multi_impl(scenes, n_scenes, params, acc.as<double>(), ray_count, stats, nullptr)) return rc;
+        if (rgb_accum) HIP_TRY(hipMemcpy(rgb_accum, acc.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (rgba8) {
+            if (int rc = img.alloc(n * 4)) return rc;
+            hipLaunchKernelGGL(k_tonemap, dim3(grid_for(root, n, 8)), dim3(BLOCK), 0, nullptr, static_cast<uint32_t>(n), root->dev.opts.samples_per_pixel,
+                               acc.as<double>(), img.as<uint8_t>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(rgba8, img.p, n * 4, hipMemcpyDeviceToHost));
+        }
         return RT_OK;
     });
 }

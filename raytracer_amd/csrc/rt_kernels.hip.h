@@ -1330,6 +1330,30 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap_argb_tiles(SceneDev sc, WorkL
     }
 }
 
+// Exchange step of rt_render_multi: a shard's tiles leave its frame tile-major (`packed`: tile, row, column, channel) and
+// are added into the root device's accumulation buffer.  Every pixel of a frame belongs to exactly one shard, so the sum is
+// exact (the other addends are the zeros the caller's buffer starts from, or earlier passes of the same pixels).
+__global__ __launch_bounds__(BLOCK) void k_pack_tiles(const uint32_t *tile_xy, uint32_t n_tiles, uint32_t tw, uint32_t th, uint32_t width,
+                                                     uint32_t height, const double *frame, double *packed) {
+    const uint64_t per_tile = static_cast<uint64_t>(tw) * th * 3u, total = per_tile * n_tiles;
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(BLOCK) + threadIdx.x; i < total; i += static_cast<uint64_t>(gridDim.x) * BLOCK) {
+        const uint32_t tile = static_cast<uint32_t>(i / per_tile), r = static_cast<uint32_t>(i % per_tile);
+        const uint32_t c = r % 3u, pit = r / 3u;
+        const uint32_t px = tile_xy[2 * tile] + pit % tw, py = tile_xy[2 * tile + 1] + pit / tw;
+        packed[i] = (px < width && py < height) ? frame[(static_cast<uint64_t>(py) * width + px) * 3ull + c] : 0.0;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_unpack_add_tiles(const uint32_t *tile_xy, uint32_t n_tiles, uint32_t tw, uint32_t th, uint32_t width,
+                                                           uint32_t height, const double *packed, double *accum) {
+    const uint64_t per_tile = static_cast<uint64_t>(tw) * th * 3u, total = per_tile * n_tiles;
+    for (uint64_t i = blockIdx.x * static_cast<uint64_t>(BLOCK) + threadIdx.x; i < total; i += static_cast<uint64_t>(gridDim.x) * BLOCK) {
+        const uint32_t tile = static_cast<uint32_t>(i / per_tile), r = static_cast<uint32_t>(i % per_tile);
+        const uint32_t c = r % 3u, pit = r / 3u;
+        const uint32_t px = tile_xy[2 * tile] + pit % tw, py = tile_xy[2 * tile + 1] + pit / tw;
+        if (px < width && py < height) accum[(static_cast<uint64_t>(py) * width + px) * 3ull + c] += packed[i];
+    }
+}
+
 // primary-hit AOVs of level-0 nodes (one sample per pixel): id, t, shading normal
 __global__ __launch_bounds__(BLOCK) void k_primary_aov(SceneDev sc, WorkList wl, NodePool np, uint32_t n_items,
                                                       uint32_t *out_id, double *out_t, double *out_n) {

@@ -15,7 +15,7 @@ _LIB = None
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_set_pool_bytes", "rt_render_device", "rt_tonemap_device",
     "rt_render", "rt_render_aov_device", "rt_render_aov", "rt_query_primary", "rt_trace_rays", "rt_scene_info", "rt_last_error", "rt_version",
-    "rt_render_progressive",
+    "rt_render_progressive", "rt_render_multi_device", "rt_render_multi",
     "rt_render_device_noalloc",
 ]
 
@@ -71,6 +71,10 @@ def lib():
         l.rt_render_progressive.restype = C.c_int
         l.rt_render_device_noalloc.argtypes = [vp, C.POINTER(_abi.RenderParams), vp, u64p, vp]
         l.rt_render_device_noalloc.restype = C.c_int
+        l.rt_render_multi_device.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(_abi.RenderParams), vp, u64p, C.POINTER(_abi.RenderStats), vp]
+        l.rt_render_multi_device.restype = C.c_int
+        l.rt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(_abi.RenderParams), f64p, u8p, u64p, C.POINTER(_abi.RenderStats)]
+        l.rt_render_multi.restype = C.c_int
         l.rt_query_primary.argtypes = [vp, u32p, f64p, f64p]
         l.rt_query_primary.restype = C.c_int
         l.rt_trace_rays.argtypes = [vp, C.c_uint32, f64p, f64p, f64p, C.c_int, u32p, f64p]
@@ -90,6 +94,34 @@ def _check(rc):
 
 def _p(arr, ctype):
     return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def _handles(scenes):
+    arr = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    return arr
+
+
+def render_multi(scenes, params=None, want_rgba=True, want_stats=False):
+    """rt_render_multi: one frame by several replicas of a scene (one per GPU) -> (rgb_sum, rgba8 or None, ray_count, [stats] or None)."""
+    params = params or _abi.RenderParams()
+    s0 = scenes[0]
+    acc = np.zeros((s0.height, s0.width, 3), np.float64)
+    rgba = np.zeros((s0.height, s0.width, 4), np.uint8) if want_rgba else None
+    count = C.c_uint64(0)
+    stats = (_abi.RenderStats * len(scenes))() if want_stats else None
+    _check(lib().rt_render_multi(_handles(scenes), len(scenes), C.byref(params), _p(acc, C.c_double), _p(rgba, C.c_uint8) if want_rgba else None,
+                                 C.byref(count), stats))
+    return acc, rgba, int(count.value), (list(stats) if want_stats else None)
+
+
+def render_multi_device(scenes, d_accum_ptr, params=None, stream=None, want_stats=False):
+    """rt_render_multi_device: d_accum_ptr is a device address on scenes[0]'s device (+= semantics) -> (ray_count, [stats] or None)."""
+    params = params or _abi.RenderParams()
+    count = C.c_uint64(0)
+    stats = (_abi.RenderStats * len(scenes))() if want_stats else None
+    _check(lib().rt_render_multi_device(_handles(scenes), len(scenes), C.byref(params), C.c_void_p(d_accum_ptr), C.byref(count), stats,
+                                        C.c_void_p(stream or 0)))
+    return int(count.value), (list(stats) if want_stats else None)
 
 
 class DeviceScene:

@@ -82,8 +82,20 @@ def _gather_plan(opts, world, spp, seed, tile_size, device):
     return plan
 
 
+def exchange_form(sample_shards, opts, exchange=None):
+    """Which collective assembles the frame -- decided from the call's arguments alone, BEFORE any collective is entered,
+    so that every rank takes the same one (a rank that changed its mind inside a collective would desynchronise RCCL)."""
+    if exchange is None:
+        exchange = "gather" if (sample_shards == 1 and opts is not None) else "reduce"
+    if exchange not in ("gather", "reduce"):
+        raise ValueError("exchange must be 'gather' or 'reduce'")
+    if exchange == "gather" and (sample_shards != 1 or opts is None):
+        raise ValueError("the gather form needs pure tile shards and the scene's rt_render_options")
+    return exchange
+
+
 def render_frame(render_local, accum, rank, world, spp, seed=0, tile_size=32, sample_shards=1, dist=None, opts=None,
-                 reduce_count=True):
+                 reduce_count=True, exchange=None):
     """Render this rank's shard with `render_local(params, accum) -> ray_count`
     and assemble the frame on rank 0.  `accum` is a zero-initialised torch tensor
     [h,w,3] float64 on the rank's device.  Returns (total_ray_count on rank 0, local count).
@@ -95,26 +107,21 @@ def render_frame(render_local, accum, rank, world, spp, seed=0, tile_size=32, sa
     reduce(SUM) of the full frames at 1/world of the bytes per link.  With sample
     shards pixels have several contributors and the full frames are reduce(SUM)ed.
     `reduce_count=False` leaves the ray counters to the caller (one reduce per
-    run instead of one per frame)."""
+    run instead of one per frame).  `exchange` forces "gather" or "reduce" (same value on every rank)."""
     import torch
 
+    form = exchange_form(sample_shards, opts, exchange)
     params = shard_params(rank, world, spp, seed, tile_size, sample_shards)
     local = int(render_local(params, accum))
     total = local
     if world > 1:
-        if sample_shards == 1 and opts is not None:
+        if form == "gather":
             plan = _gather_plan(opts, world, spp, seed, tile_size, accum.device)
             flat = accum.view(-1, 3)
             mine = flat[plan[rank][0]]
             parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-            try:
-                dist.gather(mine, parts, dst=0)
-            except (RuntimeError, NotImplementedError) as e:  # a backend without gather: every rank raises alike
-                if "gather" not in str(e).lower():
-                    raise
-                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-                parts = None
-            if rank == 0 and parts is not None:
+            dist.gather(mine, parts, dst=0)
+            if rank == 0:
                 for r in range(1, world):
                     idx, ok = plan[r]
                     flat[idx[ok]] = parts[r][ok]

@@ -105,6 +105,17 @@ def test_null_arrays_are_invalid_not_faults(libs):
         assert not h.value
 
 
+def test_render_multi_rejects_empty_scene_lists(libs):
+    import ctypes as C
+
+    from raytracer_amd import _abi, device
+
+    lib = device.lib()
+    n = C.c_uint64(0)
+    assert lib.rt_render_multi_device(None, 0, None, None, C.byref(n), None, None) == _abi.RT_ERR_INVALID
+    assert lib.rt_render_multi(None, 2, None, None, None, C.byref(n), None) == _abi.RT_ERR_INVALID
+
+
 def test_shard_tiles_partition_the_frame():
     """rt_shard_tiles is pure host code: the shards of a frame are disjoint and cover it."""
     import numpy as np

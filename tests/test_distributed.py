@@ -91,3 +91,61 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["parallelism"] == "tiles2"
     assert abs(line["config"]["rays_per_step"] - 147120917) <= 200 and line["value"] > 0
     assert "roofline" not in line and "cpu_baseline" not in line  # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_render_multi_one_process_two_and_three_replicas_on_one_gpu():
+    """rt_render_multi / rt_render_multi_device (one host process, a host thread and a stream per scene)
+    rehearsed with every replica on cuda:0 -- a one-GPU box has no second device, so the peer copy degenerates to a
+    device-to-device copy; everything else (tile deal, threads, pack, inbox, unpack-add, counters) is the real path.
+    The frame is bit-identical to rt_render's, whatever the number of replicas."""
+    import torch
+
+    from raytracer_amd import _abi, device
+
+    s = load_scene("scene", size=200)
+    scenes = [device.DeviceScene(s.desc, pool_bytes=2 << 30) for _ in range(3)]
+    want_acc, want_rgba, want_n, _ = scenes[0].render(_abi.RenderParams(seed=9))
+    for n in (1, 2, 3):
+        acc, rgba, rays, stats = device.render_multi(scenes[:n], _abi.RenderParams(seed=9), want_stats=True)
+        assert rays == want_n and np.array_equal(acc, want_acc) and np.array_equal(rgba, want_rgba)
+        assert sum(st.ray_count for st in stats) == want_n and all(st.camera_rays > 0 for st in stats)
+        if n > 1:  # an even deal: 8x8 tiles in Morton order
+            cams = [st.camera_rays for st in stats]
+            assert max(cams) - min(cams) <= 2 * 64 * 4
+    # device form, += semantics, a window and a sample range; twice in a row (the cached tile lists are reused, then replaced)
+    p = _abi.RenderParams(seed=9, x0=16, y0=40, x1=150, y1=180, s0=1, s1=3)
+    ref, _, n_ref, _ = scenes[0].render(p, want_rgba=False)
+    for _ in range(2):
+        d_acc = torch.ones((200, 200, 3), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        rays, _ = device.render_multi_device(scenes, d_acc.data_ptr(), p)
+        torch.cuda.synchronize()
+        assert rays == n_ref and np.array_equal(d_acc.cpu().numpy(), ref + 1.0)
+    acc, _, rays, _ = device.render_multi(scenes[:2], _abi.RenderParams(seed=9), want_rgba=False)
+    assert rays == want_n and np.array_equal(acc, want_acc)
+    # misuse is an error code
+    with pytest.raises(device.DeviceError, match="deals the tiles itself"):
+        device.render_multi(scenes[:2], _abi.RenderParams(shard_index=0, shard_count=2))
+    with pytest.raises(device.DeviceError, match="twice"):
+        device.render_multi([scenes[0], scenes[0]])
+    other = device.DeviceScene(load_scene("test", size=200).desc, pool_bytes=1 << 30)
+    with pytest.raises(device.DeviceError, match="not replicas"):
+        device.render_multi([scenes[0], other])
+
+
+@pytest.mark.gpu
+def test_bench_single_process_multi_rehearsal():
+    """`python bench.py --gpus 2` without torch.distributed.run: one process, rt_render_multi_device (both replicas on
+    cuda:0 here)."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MI355RT_BENCH_REHEARSE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pool-gib", "6"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "rt_render_multi_device" in line["config"]["parallelism"]
+    assert abs(line["config"]["rays_per_step"] - 147120917) <= 200 and line["value"] > 0
