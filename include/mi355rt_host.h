@@ -22,7 +22,7 @@ extern "C" {
 typedef struct rth_scene rth_scene; /* opaque; owns every array of its desc */
 
 /* main.rs:34-49: open + serde_json::from_reader + Scene::load_assets(parent dir)
- * + flatten.  Texture files are read from a decoded "<file>.ppm" sidecar (P6). */
+ * + flatten.  Textures are decoded in the library (rth_image_load's decoder). */
 int rth_scene_load(const char *json_path, rth_scene **out);
 /* same from a JSON string; asset paths resolve against asset_base */
 int rth_scene_load_string(const char *json, const char *asset_base, rth_scene **out);
@@ -36,6 +36,11 @@ void rth_scene_free(rth_scene *scene);
 int rth_transform_from_json(const char *json, double *m16, double *inv16, double *invt16);
 /* Camera -> cam_to_world 3x3 (src/render/raytracing_scene.rs:31-42). */
 int rth_camera_to_world(const double *pos3, const double *target3, const double *up3, double *m9);
+
+/* Texture::load (src/core/texture.rs:35-44): `image::open(path)?.to_rgb8()` for PNG (non-interlaced) and baseline /
+ * extended-sequential JPEG files.  Writes the image size; when rgb8 is non-NULL also the width*height*3 RGB bytes (row 0
+ * = top; capacity = bytes available).  RT_ERR_IO for unreadable / unsupported files (message in rth_last_error). */
+int rth_image_load(const char *path, uint32_t *width, uint32_t *height, uint8_t *rgb8, uint64_t capacity);
 
 /* Write an RGBA8 buffer as a PNG (image.save, main.rs:73); stored deflate. */
 int rth_write_png(const char *path, uint32_t w, uint32_t h, const uint8_t *rgba8);

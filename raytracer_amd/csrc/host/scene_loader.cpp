@@ -16,9 +16,15 @@
 #include "../../../include/mi355rt_host.h"
 #include "json.hpp"
 
+namespace rth {
+bool decode_image(const std::vector<uint8_t> &file, uint32_t *w, uint32_t *h, std::vector<uint8_t> *rgb, std::string *err);
+}
+
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <sstream>
 
@@ -469,21 +475,18 @@ struct Loader {
     int texture_id_for(const std::string &path) {
         for (size_t i = 0; i < texture_paths.size(); ++i)
             if (texture_paths[i] == path) return static_cast<int>(i);
-        // decoded sidecar written by tools/decode_textures.py (image::open(..).to_rgb8())
-        std::string full = (asset_base.empty() ? path : asset_base + "/" + path) + ".ppm";
+        // Texture::load (texture.rs:35-44): image::open(asset_base.join(path))?.to_rgb8()
+        const std::string full = asset_base.empty() ? path : asset_base + "/" + path;
         std::ifstream in(full, std::ios::binary);
-        if (!in) fail("failed to load texture at path \"" + path + "\": missing decoded sidecar " + full);
-        std::string magic;
-        int w = 0, h = 0, maxv = 0;
-        in >> magic >> w >> h >> maxv;
-        if (magic != "P6" || w <= 0 || h <= 0 || maxv != 255) fail("bad PPM header in " + full);
-        in.get();
-        std::vector<uint8_t> data(static_cast<size_t>(w) * h * 3);
-        in.read(reinterpret_cast<char *>(data.data()), static_cast<std::streamsize>(data.size()));
-        if (static_cast<size_t>(in.gcount()) != data.size()) fail("truncated PPM " + full);
+        if (!in) fail("failed to load texture at path \"" + path + "\": cannot open " + full);
+        std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        uint32_t w = 0, h = 0;
+        std::vector<uint8_t> data;
+        std::string why;
+        if (!rth::decode_image(bytes, &w, &h, &data, &why)) fail("failed to load texture at path \"" + path + "\": " + why);
         texture_paths.push_back(path);
         texture_data.push_back(std::move(data));
-        rt_texture t{static_cast<uint32_t>(w), static_cast<uint32_t>(h), nullptr};
+        rt_texture t{w, h, nullptr};
         textures.push_back(t);
         return static_cast<int>(texture_paths.size()) - 1;
     }
@@ -788,6 +791,38 @@ int rth_camera_to_world(const double *pos3, const double *target3, const double 
         m9[r * 3 + 2] = z[r];
     }
     return RT_OK;
+}
+
+int rth_image_load(const char *path, uint32_t *width, uint32_t *height, uint8_t *rgb8, uint64_t capacity) {
+    if (!path || !width || !height) {
+        g_error = "null argument";
+        return RT_ERR_INVALID;
+    }
+    try {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) {
+            g_error = std::string("failed to open file: ") + path;
+            return RT_ERR_IO;
+        }
+        std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        std::vector<uint8_t> rgb;
+        std::string why;
+        if (!rth::decode_image(bytes, width, height, &rgb, &why)) {
+            g_error = std::string(path) + ": " + why;
+            return RT_ERR_IO;
+        }
+        if (rgb8) {
+            if (capacity < rgb.size()) {
+                g_error = "rgb8 buffer too small";
+                return RT_ERR_INVALID;
+            }
+            std::memcpy(rgb8, rgb.data(), rgb.size());
+        }
+        return RT_OK;
+    } catch (const std::exception &e) {
+        g_error = e.what();
+        return RT_ERR_IO;
+    }
 }
 
 }  // extern "C"

@@ -38,6 +38,8 @@ def lib():
         l.rth_camera_to_world.restype = C.c_int
         l.rth_write_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8)]
         l.rth_write_png.restype = C.c_int
+        l.rth_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_uint64]
+        l.rth_image_load.restype = C.c_int
         l.rth_last_error.restype = C.c_char_p
         _LIB = l
     return _LIB
@@ -118,6 +120,15 @@ def camera_to_world(pos, target, up):
     out = (C.c_double * 9)()
     _check(lib().rth_camera_to_world(arr(pos), arr(target), arr(up), out))
     return np.array(out[:], dtype=np.float64).reshape(3, 3)
+
+
+def image_load(path):
+    """Texture::load's `image::open(path).to_rgb8()` -> uint8 [h, w, 3]."""
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(lib().rth_image_load(os.fsencode(path), C.byref(w), C.byref(h), None, 0))
+    rgb = np.zeros((h.value, w.value, 3), np.uint8)
+    _check(lib().rth_image_load(os.fsencode(path), C.byref(w), C.byref(h), rgb.ctypes.data_as(C.POINTER(C.c_uint8)), rgb.size))
+    return rgb
 
 
 def write_png(path, rgba8):
