@@ -181,6 +181,7 @@ extern "C" {
     pub fn rt_render(scene: *mut rt_scene, params: *const rt_render_params, rgb_accum: *mut f64, rgba8: *mut u8, ray_count: *mut u64, stats: *mut rt_render_stats) -> c_int;
     pub fn rt_query_primary(scene: *mut rt_scene, prim_id: *mut u32, t: *mut f64, normal3: *mut f64) -> c_int;
     pub fn rt_trace_rays(scene: *mut rt_scene, n: u32, origin: *const f64, dir: *const f64, tmax: *const f64, shadow: c_int, prim_id: *mut u32, t: *mut f64) -> c_int;
+    pub fn rt_scene_bvh(scene: *mut rt_scene, nodes32: *mut c_void, node_capacity: u64, leaf_prim_ids: *mut u32, leaf_capacity: u64, info4: *mut u64) -> c_int;
     pub fn rt_scene_info(scene: *mut rt_scene, out8: *mut u64) -> c_int;
     pub fn rt_shard_tiles(opts: *const rt_render_options, params: *const rt_render_params, tile_xy: *mut u32, cap: u32, n_tiles: *mut u32, tile_w: *mut u32, tile_h: *mut u32) -> c_int;
     pub fn rt_last_error() -> *const c_char;

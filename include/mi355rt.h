@@ -293,6 +293,17 @@ int rt_trace_rays(rt_scene *scene, uint32_t n, const double *origin, const doubl
  * bounded / unbounded primitive counts, node / shadow pool capacities. */
 int rt_scene_info(rt_scene *scene, uint64_t *out8);
 
+/* The acceleration structure as resident on the device, for checks and reports (the counterpart of nothing in the
+ * reference: its kd-tree, src/core/bounds.rs:425-450, is private).  nodes32: HOST buffer of node_capacity 32-byte nodes
+ * = { u16 lmin[3], lmax[3], rmin[3], rmax[3]; u32 left, right } in breadth-first order, child boxes in the 16-bit frame
+ * of the scene, child ref bit 31 = leaf (bits 28..30 = primitives - 1, bits 0..27 = first leaf record);
+ * leaf_prim_ids: HOST buffer, the primitive id of every leaf record in leaf order.  Either may be NULL.
+ * info4 = { node count, leaf-record count, root ref, 1 if the tree was built on the device }.
+ * Scenes of 65,536 bounded primitives and more are built on the GPU (binned SAH, the host builder's split rule);
+ * the environment variable MI355RT_BVH=host|device forces either. */
+int rt_scene_bvh(rt_scene *scene, void *nodes32, uint64_t node_capacity, uint32_t *leaf_prim_ids, uint64_t leaf_capacity,
+                 uint64_t *info4);
+
 /* The tile partition rt_render_device uses for `params` (pure host code, no
  * GPU needed): writes up to `cap` tile origins (x,y pairs) to tile_xy and
  * returns the tile count and tile extent.  Every rank of a multi-GPU job must

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rt_bvh.h"
+#include "rt_bvh_device.hip.h"
 #include "rt_internal.h"
 #include "rt_kernels.hip.h"
 
@@ -265,6 +266,7 @@ struct rt_scene {
     uint64_t scene_bytes = 0;
     uint64_t n_nodes = 0, n_leaves = 0, bvh_depth = 0;
     int n_cus = 256;
+    bool bvh_on_device = false;  // the tree was built by rt_bvh_device.hip.h
 
     uint64_t pool_bytes = 24ull << 30;  // one batch for 800x800x4spp scene.json (108 M nodes); 8 % of the 288 GB
     void *pool_mem = nullptr;
@@ -820,8 +822,43 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
 
     lap("flatten primitives, boxes");
 
-    // ---- BVH
-    BvhBuildResult bvh = build_bvh(cull_boxes, &leaf_group);
+    // ---- BVH: on the device for large scenes (same split rule, rt_bvh_device.hip.h), on the host otherwise.
+    // MI355RT_BVH=host|device forces one of them (tests build small scenes with the device builder).
+    BvhBuildResult bvh;
+    const BvhNode *d_built_nodes = nullptr;
+    size_t n_built_nodes = 0;
+    {
+        const char *want = std::getenv("MI355RT_BVH");
+        bool on_device = want ? std::strcmp(want, "device") == 0 : n_bounded >= 65536;
+        if (on_device) {  // the device builder orders f64 bounds through integer keys: finite boxes only
+            for (size_t b = 0; b < n_bounded && on_device; ++b)
+                for (int k = 0; k < 3; ++k)
+                    if (!std::isfinite(cull_boxes[b].mn[k]) || !std::isfinite(cull_boxes[b].mx[k])) on_device = false;
+        }
+        if (on_device && n_bounded > 0) {
+            bvhdev::DeviceBuildResult dr;
+            std::string why;
+            if (!bvhdev::build_bvh_device(cull_boxes, leaf_group, &dr, &why)) return fail(RT_ERR_DEVICE, "device BVH build: " + why);
+            if (dr.d_nodes) sc->allocs.push_back(const_cast<BvhNode *>(dr.d_nodes));
+            d_built_nodes = dr.d_nodes;
+            n_built_nodes = dr.n_nodes;
+            bvh.order = std::move(dr.order);
+            bvh.root_ref = dr.root_ref;
+            bvh.max_depth = dr.max_depth;
+            bvh.n_leaves = dr.n_leaves;
+            bvh.root_box = dr.root_box;
+            for (int k = 0; k < 3; ++k) {
+                bvh.q_origin[k] = dr.q_origin[k];
+                bvh.q_scale[k] = dr.q_scale[k];
+            }
+            sc->bvh_on_device = true;
+            sc->scene_bytes += n_built_nodes * sizeof(BvhNode);
+            if (timing) std::fprintf(stderr, "rt_scene_create:   device BVH kernels %.1f ms\n", dr.ms_device);
+        } else {
+            bvh = build_bvh(cull_boxes, &leaf_group);
+            n_built_nodes = bvh.nodes.size();
+        }
+    }
     lap("BVH build");
     std::vector<LeafPrim> leaf(bvh.order.size());
     parallel_for(bvh.order.size(), [&](size_t j0, size_t j1) {
@@ -848,7 +885,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         lp.meta = sh.type | (d->materials[sh.material].side << 2) | (sh.xf << 4);
     }
     });
-    sc->n_nodes = bvh.nodes.size();
+    sc->n_nodes = n_built_nodes;
     sc->n_leaves = bvh.n_leaves;
     sc->bvh_depth = bvh.max_depth;
     lap("leaf records");
@@ -865,7 +902,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         const uint32_t stack_bytes = (bvh.max_depth + 2u) * BLOCK * static_cast<uint32_t>(sizeof(uint32_t));
         const uint32_t budget = 40u * 1024u - 2048u;  // per block; 2 KB for the kernels' static LDS (work map, live-list masks)
         const uint32_t fit = stack_bytes < budget ? (budget - stack_bytes) / static_cast<uint32_t>(sizeof(BvhNode)) : 0u;
-        dev.n_top_nodes = static_cast<uint32_t>(std::min<size_t>(bvh.nodes.size(), std::min(fit, 512u)));
+        dev.n_top_nodes = static_cast<uint32_t>(std::min<size_t>(n_built_nodes, std::min(fit, 512u)));
     }
     dev.n_planes = static_cast<uint32_t>(planes.size());
     dev.n_bounded = static_cast<uint32_t>(bounded_ids.size());
@@ -904,7 +941,8 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     int rc;
     uint64_t *bytes = &sc->scene_bytes;
     Stager st;
-    if ((rc = upload(st, bvh.nodes, &dev.nodes, sc->allocs, bytes))) return rc;
+    if (d_built_nodes) dev.nodes = d_built_nodes;
+    else if ((rc = upload(st, bvh.nodes, &dev.nodes, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, leaf, &dev.leaf_prims, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, planes, &dev.planes, sc->allocs, bytes))) return rc;
     // get_emissive_phong (:135-167) adds a child only if reflectivity > 0; get_emissive_physical (:263-337)
@@ -1177,6 +1215,27 @@ uint32_t grid_1d(uint64_t n, uint32_t cap) { return static_cast<uint32_t>(std::m
 }  // namespace
 
 extern "C" {
+
+int rt_scene_bvh(rt_scene *s, void *nodes32, uint64_t node_capacity, uint32_t *leaf_prim_ids, uint64_t leaf_capacity, uint64_t *info4) {
+    if (!info4) return fail(RT_ERR_INVALID, "null argument");
+    return guarded_on(s, [&]() -> int {
+        info4[0] = s->n_nodes;
+        info4[1] = s->dev.n_bounded;
+        info4[2] = s->dev.root_ref;
+        info4[3] = s->bvh_on_device ? 1u : 0u;
+        if (nodes32) {
+            if (node_capacity < s->n_nodes) return fail(RT_ERR_INVALID, "node buffer too small");
+            if (s->n_nodes) HIP_TRY(hipMemcpy(nodes32, s->dev.nodes, s->n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+        }
+        if (leaf_prim_ids) {
+            if (leaf_capacity < s->dev.n_bounded) return fail(RT_ERR_INVALID, "leaf buffer too small");
+            std::vector<LeafPrim> leaf(s->dev.n_bounded);
+            if (!leaf.empty()) HIP_TRY(hipMemcpy(leaf.data(), s->dev.leaf_prims, leaf.size() * sizeof(LeafPrim), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < leaf.size(); ++i) leaf_prim_ids[i] = leaf[i].prim_id;
+        }
+        return RT_OK;
+    });
+}
 
 int rt_render_device(rt_scene *s, const rt_render_params *params, double *d_rgb_accum, uint64_t *ray_count,
                      rt_render_stats *stats, void *stream_v) {

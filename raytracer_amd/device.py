@@ -15,7 +15,7 @@ _LIB = None
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_scene_set_pool_bytes", "rt_render_device", "rt_tonemap_device",
     "rt_render", "rt_render_aov_device", "rt_render_aov", "rt_query_primary", "rt_trace_rays", "rt_scene_info", "rt_last_error", "rt_version",
-    "rt_render_progressive", "rt_render_multi_device", "rt_render_multi",
+    "rt_render_progressive", "rt_render_multi_device", "rt_render_multi", "rt_scene_bvh",
     "rt_render_device_noalloc",
 ]
 
@@ -75,6 +75,8 @@ def lib():
         l.rt_render_multi_device.restype = C.c_int
         l.rt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.POINTER(_abi.RenderParams), f64p, u8p, u64p, C.POINTER(_abi.RenderStats)]
         l.rt_render_multi.restype = C.c_int
+        l.rt_scene_bvh.argtypes = [vp, vp, C.c_uint64, u32p, C.c_uint64, u64p]
+        l.rt_scene_bvh.restype = C.c_int
         l.rt_query_primary.argtypes = [vp, u32p, f64p, f64p]
         l.rt_query_primary.restype = C.c_int
         l.rt_trace_rays.argtypes = [vp, C.c_uint32, f64p, f64p, f64p, C.c_int, u32p, f64p]
@@ -140,6 +142,16 @@ class DeviceScene:
         _check(lib().rt_scene_info(self._h, out))
         keys = ["bvh_nodes", "bvh_leaves", "bvh_depth", "scene_bytes", "bounded", "planes", "node_capacity", "shadow_capacity"]
         return dict(zip(keys, [int(v) for v in out]))
+
+    def bvh(self):
+        """rt_scene_bvh -> (nodes structured array, leaf primitive ids, root ref, built_on_device)."""
+        info = (C.c_uint64 * 4)()
+        _check(lib().rt_scene_bvh(self._h, None, 0, None, 0, info))
+        node_t = np.dtype([("lmin", "<u2", 3), ("lmax", "<u2", 3), ("rmin", "<u2", 3), ("rmax", "<u2", 3), ("left", "<u4"), ("right", "<u4")])
+        nodes = np.zeros(int(info[0]), node_t)
+        ids = np.zeros(int(info[1]), np.uint32)
+        _check(lib().rt_scene_bvh(self._h, nodes.ctypes.data_as(C.c_void_p), len(nodes), _p(ids, C.c_uint32), len(ids), info))
+        return nodes, ids, int(info[2]), bool(info[3])
 
     def render(self, params=None, want_rgba=True, want_stats=False):
         """Host-buffer render -> (rgb_sum[h,w,3] f64, rgba8[h,w,4] or None, ray_count, stats or None)."""
