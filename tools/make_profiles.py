@@ -80,4 +80,13 @@ def valu(paths):
 
 
 if __name__ == "__main__":
-    print(json.dumps({"traffic": traffic, "valu": valu}[sys.argv[1]](sys.argv[2:]), indent=1))
+    # usage: make_profiles.py traffic|valu [--tree TAG] CSV...   (TAG = the profiles/ prefix of the tree the passes ran on)
+    args = sys.argv[2:]
+    tree = None
+    if args and args[0] == "--tree":
+        tree, args = args[1], args[2:]
+    out = {"traffic": traffic, "valu": valu}[sys.argv[1]](args)
+    if tree:
+        out["_tree"] = tree
+    out["_frames"] = 2
+    print(json.dumps(out, indent=1))
