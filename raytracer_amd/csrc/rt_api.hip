@@ -247,6 +247,7 @@ enum { CLS_RAYGEN = 0, CLS_CLOSEST, CLS_SHADOW, CLS_EXPAND, CLS_RESOLVE, CLS_ACC
 struct RenderCtx {
     NodePool np{};
     ShadowPool sp{};
+    GiPool gp{};
     Counters *d_ctr = nullptr;
     Counters *h_ctr = nullptr;  // host copy of the counters (pinned for a scene's own context)
     uint32_t *d_tiles = nullptr;
@@ -256,7 +257,17 @@ struct RenderCtx {
     rt_render_params plan_key{};
     WorkList plan_wl{};
     bool plan_scattered = false;  // plan_wl is in scattered order (a call of several batches)
-    double est_nodes_per_item = 0.0, est_shadows_per_item = 0.0;
+    double est_nodes_per_item = 0.0, est_shadows_per_item = 0.0, est_jobs_per_item = 0.0, est_specials_per_item = 0.0;
+    // camera rays one batch can hold, from the largest expansion seen so far (0: nothing seen yet)
+    double fit_items() const {
+        if (!(est_nodes_per_item > 0.0)) return 0.0;
+        double fit = np.capacity / est_nodes_per_item;
+        fit = std::min(fit, sp.capacity / std::max(est_shadows_per_item, 1e-9));
+        fit = std::min(fit, gp.job_capacity / std::max(est_jobs_per_item, 1e-9));
+        fit = std::min(fit, gp.special_capacity / std::max(est_specials_per_item, 1e-9));
+        return fit;
+    }
+    void forget_estimates() { est_nodes_per_item = est_shadows_per_item = est_jobs_per_item = est_specials_per_item = 0.0; }
 };
 
 struct rt_scene {
@@ -318,16 +329,19 @@ struct rt_scene {
 
 namespace {
 
-// bytes of pool per node: ray 64 + hit 28 + expansion info 16 + live 4 = 112; per shadow ray 34; one shadow ray per two nodes
-constexpr uint64_t POOL_BYTES_PER_NODE = 112 + 34 / 2 + 8;
+// Pool shares.  With the GI rays traced in place a frame's nodes are the camera rays, reflection / refraction children
+// and the 1-in-10 GI rays that go on; shadow rays outnumber them (scene.json: 36 M nodes, 39 M shadow rays, 14 M GI jobs,
+// 7 M specials).  Per node: ray 64 + hit 28 + expansion info 16 + live 4 + job index 4 = 116 bytes; 1.5 shadow rays of 34
+// bytes; half a GI job of 80 bytes; one special of 8 bytes.  Batches are sized from the measured use of every pool.
+constexpr uint64_t POOL_BYTES_PER_NODE = 116 + 51 + 40 + 8 + 8;
 
-// Carves the node and shadow pools out of [mem, mem + bytes).  No allocation.
-int carve_pools(void *mem, uint64_t bytes, NodePool *np_out, ShadowPool *sp_out) {
+// Carves the node, shadow and GI pools out of [mem, mem + bytes).  No allocation.
+int carve_pools(void *mem, uint64_t bytes, NodePool *np_out, ShadowPool *sp_out, GiPool *gp_out) {
     uint64_t cap = bytes / POOL_BYTES_PER_NODE;
-    cap = std::min<uint64_t>(cap, 1ull << 31);
+    cap = std::min<uint64_t>(cap, 1ull << 30);
     cap &= ~uint64_t(255);
     if (cap < 4096) return fail(RT_ERR_NOMEM, "pool budget too small");
-    uint64_t scap = (cap / 2) & ~uint64_t(255);
+    uint64_t scap = (cap + cap / 2) & ~uint64_t(255);
     char *p = static_cast<char *>(mem);
     auto take = [&](uint64_t n) {
         char *r = p;
@@ -347,7 +361,13 @@ int carve_pools(void *mem, uint64_t bytes, NodePool *np_out, ShadowPool *sp_out)
     np.prim = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.xinfo = reinterpret_cast<ExpandInfo *>(take(cap * 16));
     np.live = reinterpret_cast<uint32_t *>(take(cap * 4));
+    np.gi_job = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.capacity = static_cast<uint32_t>(cap);
+    GiPool &gp = *gp_out;
+    gp.job_capacity = static_cast<uint32_t>((cap / 2) & ~uint64_t(255));
+    gp.special_capacity = static_cast<uint32_t>(cap);
+    gp.jobs = reinterpret_cast<GiJob *>(take(static_cast<uint64_t>(gp.job_capacity) * sizeof(GiJob)));
+    gp.specials = reinterpret_cast<GiSpecial *>(take(static_cast<uint64_t>(gp.special_capacity) * sizeof(GiSpecial)));
     ShadowPool &sp = *sp_out;
     sp.s0 = reinterpret_cast<Vec2d *>(take(scap * 16));
     sp.s1 = reinterpret_cast<Vec2d *>(take(scap * 16));
@@ -373,10 +393,10 @@ int ensure_pools(rt_scene *s) {
     if (want < (1ull << 20)) return fail(RT_ERR_NOMEM, "less than 1 MiB of device memory free for the wavefront pools");
     HIP_TRY(hipMalloc(&s->pool_mem, want));
     s->pool_mem_bytes = s->pool_bytes;  // the budget this allocation answers (may be clamped)
-    if (int rc = carve_pools(s->pool_mem, want, &ctx.np, &ctx.sp)) return rc;
+    if (int rc = carve_pools(s->pool_mem, want, &ctx.np, &ctx.sp, &ctx.gp)) return rc;
     if (!ctx.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx.d_ctr), MAX_SHARDS * sizeof(Counters)));
     if (!ctx.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx.h_ctr), MAX_SHARDS * sizeof(Counters)));
-    ctx.est_nodes_per_item = ctx.est_shadows_per_item = 0.0;
+    ctx.forget_estimates();
     ctx.plan_valid = false;
     return RT_OK;
 }
@@ -443,10 +463,8 @@ int plan_tiles(const rt_render_options &o, const rt_render_params *prm, std::vec
 // Camera rays of the first batch of a call (later batches are sized from the expansion the earlier ones showed).
 uint64_t first_batch_items(const RenderCtx &c, uint64_t total_items, uint32_t ns) {
     uint64_t batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, c.np.capacity / 64));
-    if (c.est_nodes_per_item > 0.0) {
-        const double fit = std::min(c.np.capacity / c.est_nodes_per_item, c.sp.capacity / std::max(c.est_shadows_per_item, 1e-9));
-        batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, static_cast<uint64_t>(0.7 * fit)));
-    }
+    const double fit = c.fit_items();
+    if (fit > 0.0) batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, static_cast<uint64_t>(0.7 * fit)));
     return batch;
 }
 
@@ -533,6 +551,14 @@ int plan_call(rt_scene *s, RenderCtx &c, const rt_render_params *prm, CallPlan *
     return RT_OK;
 }
 
+// raytracing_scene.rs:104-105 on the host (the kernels' gi_rays)
+uint32_t gi_rays_host(const rt_render_options &o, uint32_t depth) {
+    uint32_t d = 1;
+    for (uint32_t i = 0; i < depth; ++i) d *= 4u;
+    const uint32_t n = o.max_illumination_rays / d;
+    return n < 1u ? 1u : n;
+}
+
 uint32_t grid_for(const rt_scene *s, uint64_t n, uint32_t blocks_per_cu) {
     uint64_t need = (n + BLOCK - 1) / BLOCK;
     uint64_t cap = static_cast<uint64_t>(s->n_cus) * blocks_per_cu;
@@ -556,6 +582,8 @@ Shards plan_shards(const RenderCtx &c, uint64_t n, uint32_t ns) {
     if (k == 1) sh.granule = ns;  // no padding items in small batches
     sh.node_cap = c.np.capacity / k;
     sh.shadow_cap = c.sp.capacity / k;
+    sh.job_cap = c.gp.job_capacity / k;
+    sh.special_cap = c.gp.special_capacity / k;
     return sh;
 }
 
@@ -566,7 +594,16 @@ uint32_t stack_lds_bytes(const rt_scene *s) {
     return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + s->dev.n_top_nodes * static_cast<uint32_t>(sizeof(BvhNode)) + extra;
 }
 
-Shards single_shard(const RenderCtx &c) { return Shards{1u, c.np.capacity, c.sp.capacity, 1u}; }
+Shards single_shard(const RenderCtx &c) {
+    Shards sh{};
+    sh.count = 1u;
+    sh.node_cap = c.np.capacity;
+    sh.shadow_cap = c.sp.capacity;
+    sh.job_cap = c.gp.job_capacity;
+    sh.special_cap = c.gp.special_capacity;
+    sh.granule = 1u;
+    return sh;
+}
 
 // ---------------------------------------------------------------- the library's static device scratch
 // rt_render_device_noalloc renders with every pool, counter and tile list in this array instead of hipMalloc'ed memory.
@@ -604,7 +641,7 @@ int scratch_for_device(int device, void **out) {
         c.d_tiles_cap = SCRATCH_MAX_TILES;
         c.can_grow = false;
         c.h_ctr = f.h_ctr;
-        if (int rc = carve_pools(base + SCRATCH_CTR_BYTES + SCRATCH_TILE_BYTES, SCRATCH_POOL_BYTES, &c.np, &c.sp)) return rc;
+        if (int rc = carve_pools(base + SCRATCH_CTR_BYTES + SCRATCH_TILE_BYTES, SCRATCH_POOL_BYTES, &c.np, &c.sp, &c.gp)) return rc;
         f.ptr = ptr;
     }
     *out = f.ptr;
@@ -688,7 +725,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         return fail(RT_ERR_INVALID, "u16 option out of range");
     if (o.max_illumination_rays > 16383) return fail(RT_ERR_UNSUPPORTED, "max_illumination_rays > 16383");
     if (d->n_lights > 255) return fail(RT_ERR_UNSUPPORTED, "more than 255 lights");
-    if (d->n_materials >= (1u << 24)) return fail(RT_ERR_UNSUPPORTED, "too many materials");
+    if (d->n_materials >= (1u << 23)) return fail(RT_ERR_UNSUPPORTED, "too many materials");
     uint32_t n_point = 0;
     for (uint32_t i = 0; i < d->n_lights; ++i) n_point += d->lights[i].kind == RT_LIGHT_POINT ? 1u : 0u;
     if (n_point > 32) return fail(RT_ERR_UNSUPPORTED, "more than 32 point lights");
@@ -1047,6 +1084,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     const uint32_t max_depth = s->dev.opts.max_depth;
     const NodePool &np = ctx.np;
     const ShadowPool &sp = ctx.sp;
+    const GiPool &gp = ctx.gp;
     Counters *d_ctr = ctx.d_ctr;
 
     rt_render_stats st{};
@@ -1061,7 +1099,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     }
 
     uint64_t item0 = 0;
-    double call_max_nodes = 0.0, call_max_shadows = 0.0;
+    double call_max[4] = {0.0, 0.0, 0.0, 0.0};  // nodes, shadow rays, GI jobs, GI specials per camera ray: the largest of the call's batches
     // first batch: modest guess, later batches sized from the measured expansion
     uint64_t batch = first_batch_items(ctx, plan.total_items, wl.ns);
     const uint32_t gmax = static_cast<uint32_t>(s->n_cus) * 8u;
@@ -1093,8 +1131,16 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
                 timer.begin(CLS_EXPAND);
                 hipLaunchKernelGGL(k_build_live, dim3(level == 0 ? shard_grid(s, sh, n / 4 + 1, 8) : g_wide), dim3(BLOCK), 0, stream, np, d_ctr, sh, level);
                 const uint32_t ge = level == 0 ? shard_grid(s, sh, n, 8) : g_wide;
-                if (count_work) hipLaunchKernelGGL(k_expand<true>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, d_ctr, sh, level);
-                else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, d_ctr, sh, level);
+                if (count_work) hipLaunchKernelGGL(k_expand<true>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, gp, d_ctr, sh, level);
+                else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, gp, d_ctr, sh, level);
+                timer.end();
+                if (level + 1 < max_depth && gi_rays_host(s->dev.opts, level) <= GI_MAX_INPLACE) {  // the GI rays of this level's hits, in place
+                    timer.begin(CLS_CLOSEST);
+                    if (count_work) hipLaunchKernelGGL(k_trace_gi<true>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, wl, np, gp, d_ctr, sh, level + 1, stack_entries(s));
+                    else hipLaunchKernelGGL(k_trace_gi<false>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, wl, np, gp, d_ctr, sh, level + 1, stack_entries(s));
+                    timer.end();
+                }
+                timer.begin(CLS_EXPAND);
                 hipLaunchKernelGGL(k_advance_level, dim3(1), dim3(64), 0, stream, d_ctr, sh, level);
                 timer.end();
             }
@@ -1107,8 +1153,8 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
             for (uint32_t level = max_depth; level-- > 0;) {
                 timer.begin(CLS_RESOLVE);
                 const dim3 gr(level == 0 ? shard_grid(s, sh, n, 8) : g_wide);
-                if (level > 0) hipLaunchKernelGGL(k_resolve<true>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, d_ctr, sh, level, 0u);  // camera rays are colour nodes
-                hipLaunchKernelGGL(k_resolve<false>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, d_ctr, sh, level, aov);
+                if (level > 0) hipLaunchKernelGGL(k_resolve<true>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, gp, d_ctr, sh, level, 0u);  // camera rays are colour nodes
+                hipLaunchKernelGGL(k_resolve<false>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, gp, d_ctr, sh, level, aov);
                 timer.end();
             }
             timer.begin(CLS_ACCUM);
@@ -1125,6 +1171,10 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
             for (uint32_t l = 0; l <= MAX_LEVELS; ++l) c.level_count[l] += ck.level_count[l];
             c.node_alloc += ck.node_alloc;
             c.shadow_alloc += ck.shadow_alloc;
+            c.job_alloc += ck.job_alloc;
+            c.special_alloc += ck.special_alloc;
+            c.gi_rays += ck.gi_rays;
+            c.gi_materialised += ck.gi_materialised;
             c.overflow |= ck.overflow;
             c.active_camera += ck.active_camera;
             c.nodes_visited_closest += ck.nodes_visited_closest;
@@ -1157,13 +1207,14 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         if (c.overflow) {
             if (n <= wl.ns) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's ray tree");
             batch = std::max<uint64_t>(wl.ns, (n / 2) - (n / 2) % wl.ns);
-            ctx.est_nodes_per_item = 0.0;
+            ctx.forget_estimates();
             st.retries += 1;
             continue;  // re-run the same range with a smaller batch; nothing was accumulated
         }
         // ---- statistics (reference counting rule: +1 per traced get_color/get_illumination, +1 per shadow ray)
         uint64_t closest = c.active_camera;
         for (uint32_t l = 1; l <= max_depth && l <= MAX_LEVELS; ++l) closest += c.level_count[l];
+        closest += c.gi_rays - c.gi_materialised;  // GI rays traced in place; the ones that got a node are in level_count already
         if (max_depth == 0) closest = 0;
         st.closest_rays += closest;
         st.shadow_rays += c.shadow_alloc;
@@ -1186,18 +1237,23 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         // expansion varies over the image: size later batches (and later calls) from the
         // LARGEST expansion seen, not the last one, so a cheap final batch cannot
         // provoke an overflow + re-run at the start of the next frame
-        call_max_nodes = std::max(call_max_nodes, static_cast<double>(c.node_alloc) / static_cast<double>(n));
-        call_max_shadows = std::max(call_max_shadows, static_cast<double>(c.shadow_alloc) / static_cast<double>(n));
-        ctx.est_nodes_per_item = std::max(ctx.est_nodes_per_item, call_max_nodes);
-        ctx.est_shadows_per_item = std::max(ctx.est_shadows_per_item, call_max_shadows);
-        double fit = std::min(np.capacity / std::max(ctx.est_nodes_per_item, 1.0),
-                              sp.capacity / std::max(ctx.est_shadows_per_item, 1e-9));
-        batch = std::max<uint64_t>(wl.ns, static_cast<uint64_t>(0.7 * fit));
+        const double dn = static_cast<double>(n);
+        call_max[0] = std::max(call_max[0], static_cast<double>(c.node_alloc) / dn);
+        call_max[1] = std::max(call_max[1], static_cast<double>(c.shadow_alloc) / dn);
+        call_max[2] = std::max(call_max[2], static_cast<double>(c.job_alloc) / dn);
+        call_max[3] = std::max(call_max[3], static_cast<double>(c.special_alloc) / dn);
+        ctx.est_nodes_per_item = std::max(ctx.est_nodes_per_item, call_max[0]);
+        ctx.est_shadows_per_item = std::max(ctx.est_shadows_per_item, call_max[1]);
+        ctx.est_jobs_per_item = std::max(ctx.est_jobs_per_item, call_max[2]);
+        ctx.est_specials_per_item = std::max(ctx.est_specials_per_item, call_max[3]);
+        batch = std::max<uint64_t>(wl.ns, static_cast<uint64_t>(0.7 * ctx.fit_items()));
         item0 += n;
     }
-    if (call_max_nodes > 0.0) {  // forget stale maxima of earlier calls (other windows / shards)
-        ctx.est_nodes_per_item = call_max_nodes;
-        ctx.est_shadows_per_item = call_max_shadows;
+    if (call_max[0] > 0.0) {  // forget stale maxima of earlier calls (other windows / shards)
+        ctx.est_nodes_per_item = call_max[0];
+        ctx.est_shadows_per_item = call_max[1];
+        ctx.est_jobs_per_item = call_max[2];
+        ctx.est_specials_per_item = call_max[3];
     }
     st.ray_count = st.closest_rays + st.shadow_rays;
     if (stats) {
@@ -1272,7 +1328,7 @@ int rt_render_device_noalloc(rt_scene *s, const rt_render_params *params, double
         if (f.ptr != s->scratch) return fail(RT_ERR_DEVICE, "internal: scratch address mismatch");
         // the scratch is shared by every scene on this device: its plan cache and expansion estimates belong to the last caller
         f.ctx.plan_valid = false;
-        f.ctx.est_nodes_per_item = f.ctx.est_shadows_per_item = 0.0;
+        f.ctx.forget_estimates();
         return render_impl(s, f.ctx, params, d_rgb_accum, nullptr, nullptr, ray_count, nullptr, static_cast<hipStream_t>(stream_v));
     });
 }

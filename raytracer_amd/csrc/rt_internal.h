@@ -132,13 +132,15 @@ struct SceneDev {
 //   bit  6     probe ray of rt_trace_rays (treated as Secondary)
 //   bit  7     done: the trace kernel already wrote the node's final result (misses,
 //              illumination nodes that hit a surface with nothing to gather)
-//   bits 8..31 material of the parent hit (valid when bit 4)
+//   bit  8     traced: the hit fields are already filled in (a GI ray that k_trace_gi found to need a node of its own)
+//   bits 9..31 material of the parent hit (valid when bit 4)
 constexpr uint32_t META_DEPTH_MASK = 7u;
 constexpr uint32_t META_ILLUM = 8u;
 constexpr uint32_t META_REFR = 16u;
 constexpr uint32_t META_INACTIVE = 32u;
 constexpr uint32_t META_DONE = 128u;  // bit 7: result already final (set by k_trace_closest), nothing to expand or resolve
-constexpr uint32_t META_MAT_SHIFT = 8u;
+constexpr uint32_t META_TRACED = 256u;  // bit 8
+constexpr uint32_t META_MAT_SHIFT = 9u;
 
 // Node pool: structure of arrays of 16-byte elements where a record's fields travel
 // together (one 16-byte access per lane is the widest, and a wave's 64 of them are
@@ -153,6 +155,32 @@ struct alignas(16) ExpandInfo {
     uint32_t counts;      // nR | nT << 16 | nG << 17
     uint32_t light_mask;  // point lights that cast a shadow ray
 };
+// GI rays in place (compute_global_illumination, raytracing_scene.rs:98-133).  3 of 4 closest-hit rays of a frame are GI
+// rays and 9 of 10 of those end at once (a miss, or a surface whose get_illumination gathers nothing), so they get no
+// node record: k_expand leaves ONE job per colour node -- what is needed to draw its G(d) hemisphere rays -- and
+// k_trace_gi generates, traces and reduces them per job.  What a parent needs back: how many rays were unoccluded, and
+// -- in slot order, so that the f64 sum of :121 keeps its order -- the few rays whose emissive contribution is not zero:
+// a terminal hit on an emissive surface (kind 0: primitive id) or a hit that needs shading of its own and got a node
+// (kind 1: node index, resolved one level down before the parent reads it).
+struct alignas(16) GiJob {
+    double P[3], n[3];  // hit point, shading normal
+    uint64_t path;      // the parent's RNG path
+    uint32_t root;      // camera-ray item
+    uint32_t pixel, sample;
+    uint32_t unoccluded, n_special, first_special;  // results
+};
+static_assert(sizeof(GiJob) == 80, "GiJob must be 80 bytes");
+struct GiSpecial {
+    uint32_t slot_kind;  // bits 0..30 slot g, bit 31 kind
+    uint32_t id;         // kind 0: primitive id (terminal hit, emissive surface); kind 1: node index
+};
+constexpr uint32_t GI_MAX_INPLACE = 64;  // G(d) above a wave's width: the rays are materialised as nodes (the round-1 path)
+struct GiPool {
+    GiJob *jobs;
+    GiSpecial *specials;
+    uint32_t job_capacity, special_capacity;
+};
+
 struct NodePool {
     Vec2d *r0, *r1, *r2;  // ray: (o.x, o.y) (o.z, d.x) (d.y, d.z)
     uint64_t *path;
@@ -166,6 +194,7 @@ struct NodePool {
     // by the trace kernel into the level's own index range of this array -- colour nodes from the range's start
     // upwards, illumination nodes from its end downwards (Counters::live_colour / live_illum count them).
     uint32_t *live;
+    uint32_t *gi_job;  // colour nodes whose GI rays are traced in place: index of their GiJob
     uint32_t capacity;
 };
 
@@ -182,6 +211,11 @@ struct Counters {
     uint32_t level_count[MAX_LEVELS + 1];
     unsigned long long node_alloc;    // bump pointer into the node pool
     unsigned long long shadow_alloc;  // bump pointer into the shadow pool
+    unsigned long long job_alloc;      // bump pointer into the shard's GI jobs
+    unsigned long long special_alloc;  // bump pointer into the shard's GI specials
+    uint32_t job_level_start[MAX_LEVELS + 1];  // jobs left by k_expand(level): [job_level_start[level], job_alloc) until the level is closed
+    unsigned long long gi_rays;          // GI rays traced in place
+    unsigned long long gi_materialised;  // of which got a node (also counted in level_count)
     uint32_t live_colour[MAX_LEVELS + 1], live_illum[MAX_LEVELS + 1];  // entries of NodePool::live per level
     uint32_t overflow;       // a pool ran out: the batch must be re-run smaller
     uint32_t active_camera;  // camera rays inside the window
@@ -209,6 +243,8 @@ struct Shards {
     uint32_t count;
     uint32_t node_cap;    // nodes per shard
     uint32_t shadow_cap;  // shadow rays per shard
+    uint32_t job_cap;     // GI jobs per shard
+    uint32_t special_cap; // GI specials per shard
     uint32_t granule;     // camera-ray items per deal (multiple of the samples per pixel)
 };
 

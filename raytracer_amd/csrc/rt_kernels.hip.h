@@ -55,6 +55,7 @@ __device__ __forceinline__ void item_to_pixel(const WorkList &wl, uint32_t item,
 struct ShardCtx {
     Counters *ctr;
     uint32_t node_off, shadow_off;  // first pool index of the shard
+    uint32_t job_off, special_off;
     uint32_t bid, nblocks;          // this block's index / the block count within the shard
     uint32_t shard;
 };
@@ -65,6 +66,8 @@ __device__ __forceinline__ ShardCtx shard_ctx(Counters *ctrs, const Shards &sh) 
     c.ctr = ctrs + c.shard;
     c.node_off = c.shard * sh.node_cap;
     c.shadow_off = c.shard * sh.shadow_cap;
+    c.job_off = c.shard * sh.job_cap;
+    c.special_off = c.shard * sh.special_cap;
     c.bid = blockIdx.x / sh.count;
     c.nblocks = gridDim.x / sh.count;
     return c;
@@ -322,6 +325,10 @@ __global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
     ctr->level_count[0] = local;  // items past n_items are padding (META_INACTIVE)
     ctr->node_alloc = local;
     ctr->shadow_alloc = 0;
+    ctr->job_alloc = 0;
+    ctr->special_alloc = 0;
+    for (uint32_t i = 0; i <= MAX_LEVELS; ++i) ctr->job_level_start[i] = 0;
+    ctr->gi_rays = ctr->gi_materialised = 0;
     ctr->overflow = local > sh.node_cap ? 1u : 0u;
     ctr->active_camera = 0;
     ctr->nodes_visited_closest = ctr->prims_tested_closest = 0;
@@ -338,7 +345,9 @@ __global__ void k_advance_level(Counters *ctrs, Shards sh, uint32_t level) {
     if (blockIdx.x != 0 || k >= sh.count) return;
     Counters *ctr = ctrs + k;
     uint32_t start = ctr->level_start[level] + ctr->level_count[level];
-    if (ctr->node_alloc > sh.node_cap || ctr->shadow_alloc > sh.shadow_cap) ctr->overflow = 1;
+    if (ctr->node_alloc > sh.node_cap || ctr->shadow_alloc > sh.shadow_cap || ctr->job_alloc > sh.job_cap || ctr->special_alloc > sh.special_cap)
+        ctr->overflow = 1;
+    ctr->job_level_start[level + 1] = static_cast<uint32_t>(ctr->job_alloc);  // k_expand(level + 1) appends from here
     ctr->level_start[level + 1] = start;
     ctr->level_count[level + 1] = ctr->overflow ? 0u : static_cast<uint32_t>(ctr->node_alloc) - start;
 }
@@ -571,6 +580,81 @@ __device__ __forceinline__ uint32_t descend(const SceneDev &sc, const uint4 *top
     return cur;
 }
 
+// KdTreeAccelerator::raycast (bounds.rs:302-308) for one ray, in the traversal-order independent form: the unbounded
+// objects, then the BVH; minimum of (t, bounded?, primitive id).  Shared by k_trace_closest and k_trace_gi.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const SceneDev &sc, const uint4 *top_nodes, uint32_t *stack, const RayD &ray, Counters *ctr,
+                                            unsigned long long &n_nodes, unsigned long long &n_prims, uint32_t *id_out, double *t_out,
+                                            double *bu_out, double *bv_out) {
+    double best_t = __builtin_inf();
+    uint32_t best_id = RT_NO_HIT;
+    double best_bu = 0.0, best_bv = 0.0;
+    bool best_bounded = false;
+
+    for (uint32_t p = 0; p < sc.n_planes; ++p) {  // unbounded objects first (bounds.rs:303-305)
+        const PlanePrim pl = sc.planes[p];
+        const double *inv = sc.inv_world + 12ull * (pl.meta >> 4);
+        RayD orr;
+        orr.o = xf_point(inv, ray.o);
+        orr.d = xf_vector(inv, ray.d);
+        HitRec h;
+        if (COUNT) n_prims++;
+        if (hit_plane(mk3(pl.normal[0], pl.normal[1], pl.normal[2]), (pl.meta >> 2) & 3u, false, orr, false, 0.0,
+                      &h) &&
+            (best_id == RT_NO_HIT || h.t < best_t)) {
+            best_t = h.t;
+            best_id = pl.prim_id;
+        }
+    }
+
+    if (sc.root_ref != 0xFFFFFFFFu) {
+        const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
+        ObjRayCache cache;
+        cache.xf = 0xFFFFFFFFu;
+        stack[0] = STACK_SENTINEL;
+        uint32_t sp = 1;
+        uint32_t cur = sc.root_ref;
+        while (true) {
+            cur = descend<COUNT>(sc, top_nodes, cr, cull_limit_f32(cull_limit(best_t)), cur, stack, sp, n_nodes);
+            if (cur == STACK_SENTINEL) break;
+            const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
+            if (COUNT && (threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(__ballot(true)) - 1)) n_prims += 1ull << 40;  // wave-level leaf round
+            for (uint32_t k = 0; k < n; ++k) {
+                const LeafPrim *lp = sc.leaf_prims + first + k;
+                HitRec h;
+                if (COUNT) n_prims++;
+                uint32_t exact_box = 0, pid, ty = 0;
+                const bool leaf_hit = test_leaf_prim<false>(sc, lp, ray, cache, 0.0, &h, &pid, COUNT ? &ty : nullptr, COUNT ? &exact_box : nullptr);
+                if (COUNT) {  // census of the wave's leaf round: which primitive types are present, how many lanes, exact box tests
+                    const unsigned long long m_all = __ballot(true), m_t = __ballot(ty == RT_PRIM_TRIANGLE), m_s = __ballot(ty == RT_PRIM_SPHERE),
+                                             m_c = __ballot(ty == RT_PRIM_CUBE), m_x = __ballot(exact_box != 0), m_h = __ballot(leaf_hit);
+                    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(m_all) - 1)) {
+                        atomicAdd(&ctr->leaf_census[(m_t ? 1 : 0) | (m_s ? 2 : 0) | (m_c ? 4 : 0) | (m_x ? 8 : 0)], 1ull);
+                        atomicAdd(&ctr->leaf_lanes[0], static_cast<unsigned long long>(__popcll(m_all)));
+                        atomicAdd(&ctr->leaf_lanes[1], static_cast<unsigned long long>(__popcll(m_x)));
+                        atomicAdd(&ctr->leaf_lanes[2], static_cast<unsigned long long>(__popcll(m_h)));
+                    }
+                }
+                if (leaf_hit) {
+                    bool better = best_id == RT_NO_HIT || h.t < best_t || (h.t == best_t && best_bounded && pid < best_id);
+                    if (better) {
+                        best_t = h.t;
+                        best_id = pid;
+                        best_bu = h.bu;
+                        best_bv = h.bv;
+                        best_bounded = true;
+                    }
+                }
+            }
+            cur = stack[(--sp) * BLOCK];
+        }
+    }
+    *id_out = best_id;
+    *t_out = best_t;
+    *bu_out = best_bu;
+    *bv_out = best_bv;
+}
+
 // KdTreeAccelerator::raycast semantics, traversal-order independent form
 // (DESIGN.md "canonical hit"): minimum of (t, bounded?, primitive id).
 //
@@ -599,71 +683,12 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
             np.prim[idx] = RT_NO_HIT;
             continue;
         }
+        if (meta & META_TRACED) continue;  // a GI ray k_trace_gi gave a node of its own: hit already stored
         RayD ray;
         load_ray(np, idx, &ray.o, &ray.d);
-        double best_t = __builtin_inf();
-        uint32_t best_id = RT_NO_HIT;
-        double best_bu = 0.0, best_bv = 0.0;
-        bool best_bounded = false;
-
-        for (uint32_t p = 0; p < sc.n_planes; ++p) {  // unbounded objects first (bounds.rs:303-305)
-            const PlanePrim pl = sc.planes[p];
-            const double *inv = sc.inv_world + 12ull * (pl.meta >> 4);
-            RayD orr;
-            orr.o = xf_point(inv, ray.o);
-            orr.d = xf_vector(inv, ray.d);
-            HitRec h;
-            if (COUNT) n_prims++;
-            if (hit_plane(mk3(pl.normal[0], pl.normal[1], pl.normal[2]), (pl.meta >> 2) & 3u, false, orr, false, 0.0,
-                          &h) &&
-                (best_id == RT_NO_HIT || h.t < best_t)) {
-                best_t = h.t;
-                best_id = pl.prim_id;
-            }
-        }
-
-        if (sc.root_ref != 0xFFFFFFFFu) {
-            const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
-            ObjRayCache cache;
-            cache.xf = 0xFFFFFFFFu;
-            stack[0] = STACK_SENTINEL;
-            uint32_t sp = 1;
-            uint32_t cur = sc.root_ref;
-            while (true) {
-                cur = descend<COUNT>(sc, top_nodes, cr, cull_limit_f32(cull_limit(best_t)), cur, stack, sp, n_nodes);
-                if (cur == STACK_SENTINEL) break;
-                const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
-                if (COUNT && (threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(__ballot(true)) - 1)) n_prims += 1ull << 40;  // wave-level leaf round
-                for (uint32_t k = 0; k < n; ++k) {
-                    const LeafPrim *lp = sc.leaf_prims + first + k;
-                    HitRec h;
-                    if (COUNT) n_prims++;
-                    uint32_t exact_box = 0, pid, ty = 0;
-                    const bool leaf_hit = test_leaf_prim<false>(sc, lp, ray, cache, 0.0, &h, &pid, COUNT ? &ty : nullptr, COUNT ? &exact_box : nullptr);
-                    if (COUNT) {  // census of the wave's leaf round: which primitive types are present, how many lanes, exact box tests
-                        const unsigned long long m_all = __ballot(true), m_t = __ballot(ty == RT_PRIM_TRIANGLE), m_s = __ballot(ty == RT_PRIM_SPHERE),
-                                                 m_c = __ballot(ty == RT_PRIM_CUBE), m_x = __ballot(exact_box != 0), m_h = __ballot(leaf_hit);
-                        if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(m_all) - 1)) {
-                            atomicAdd(&ctr->leaf_census[(m_t ? 1 : 0) | (m_s ? 2 : 0) | (m_c ? 4 : 0) | (m_x ? 8 : 0)], 1ull);
-                            atomicAdd(&ctr->leaf_lanes[0], static_cast<unsigned long long>(__popcll(m_all)));
-                            atomicAdd(&ctr->leaf_lanes[1], static_cast<unsigned long long>(__popcll(m_x)));
-                            atomicAdd(&ctr->leaf_lanes[2], static_cast<unsigned long long>(__popcll(m_h)));
-                        }
-                    }
-                    if (leaf_hit) {
-                        bool better = best_id == RT_NO_HIT || h.t < best_t || (h.t == best_t && best_bounded && pid < best_id);
-                        if (better) {
-                            best_t = h.t;
-                            best_id = pid;
-                            best_bu = h.bu;
-                            best_bv = h.bv;
-                            best_bounded = true;
-                        }
-                    }
-                }
-                cur = stack[(--sp) * BLOCK];
-            }
-        }
+        double best_t, best_bu, best_bv;
+        uint32_t best_id;
+        closest_hit<COUNT>(sc, top_nodes, stack, ray, ctr, n_nodes, n_prims, &best_id, &best_t, &best_bu, &best_bv);
         if (FINALIZE) {
             bool done = best_id == RT_NO_HIT;
             uint32_t flag = 0;
@@ -710,6 +735,133 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
             atomicMax(&ctr->wave_max_steps, ws);
             atomicAdd(&ctr->wave_iterations, 1ull);
         }
+    }
+}
+
+// compute_global_illumination (:98-133) in place: the G(d) hemisphere rays of every job k_expand(level - 1) left are
+// drawn, traced and reduced here; `level` is the depth of the GI rays.  Lanes map to whole jobs (64 / G jobs per wave
+// round, lane = job * G + slot), so the per-job reductions are ballots over aligned lane groups:
+//   unoccluded     rays whose hit distance is above max_occlusion_distance, and misses (:512-516, :123-125);
+//   specials       in slot order, the rays whose emissive contribution may be non-zero: a terminal hit on an emissive
+//                  surface (its colour is the material's), or a hit that needs get_emissive_* children (:135-167,
+//                  :263-337) -- only that ray gets a node (ray, path, hit; META_TRACED) and joins the level's nodes.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_gi(SceneDev sc, WorkList wl, NodePool np, GiPool gp, Counters *ctrs, Shards shards, uint32_t level,
+                                                   uint32_t stack_entries) {
+    extern __shared__ __align__(16) uint32_t stack_lds[];
+    uint32_t *stack = stack_lds + threadIdx.x;
+    __shared__ LevelMap map;
+    const ShardCtx c = shard_ctx(ctrs, shards);  // the shard this block ALLOCATES nodes and specials from
+    Counters *ctr = c.ctr;
+    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
+    const uint32_t G = gi_rays(sc, level - 1u);                 // rays per job (uniform over the level)
+    const uint32_t per_round = 64u / G, used = per_round * G;  // whole jobs per wave round (G <= 64)
+    // work map over the jobs of level - 1: "entries" are jobs, a group = per_round jobs
+    if (threadIdx.x < 64u) {
+        const uint32_t k = threadIdx.x;
+        uint32_t cnt = 0, over = 0;
+        if (k < shards.count) {
+            cnt = static_cast<uint32_t>(ctrs[k].job_alloc) - ctrs[k].job_level_start[level - 1u];
+            over = ctrs[k].overflow | (ctrs[k].job_alloc > shards.job_cap ? 1u : 0u);
+            map.base[k] = k * shards.job_cap + ctrs[k].job_level_start[level - 1u];
+            map.count[k] = cnt;
+        }
+        uint32_t x = (cnt + per_round - 1u) / per_round;
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            if (k >= off) x += y;
+        }
+        if (k < shards.count) map.prefix[k + 1] = x;
+        if (k == 0) map.prefix[0] = 0;
+        const unsigned long long any_over = __ballot(over != 0);
+        if (k == 0) map.dead = any_over ? 1u : 0u;
+    }
+    __syncthreads();
+    const uint32_t n_groups = map.dead ? 0u : map.prefix[shards.count];
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool next_real = level + 1u < sc.opts.max_depth;  // children of this level's hits are traced (else they return zero, :495-497)
+    unsigned long long n_nodes = 0, n_prims = 0;
+    uint32_t wave_rays = 0, wave_nodes = 0;  // wave-uniform
+    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t step = MAX_SHARDS / 2; step >= 1; step >>= 1)
+            if (k + step < shards.count && map.prefix[k + step] <= g) k += step;
+        const uint32_t first_job = (g - map.prefix[k]) * per_round, jobs_here = min(per_round, map.count[k] - first_job);
+        const uint32_t jl = lane / G, slot = lane - jl * G;
+        const bool valid = lane < used && jl < jobs_here;
+        const uint32_t job_index = map.base[k] + first_job + (valid ? jl : 0u);
+        uint32_t hit_id = RT_NO_HIT;
+        double hit_t = 0.0, hit_bu = 0.0, hit_bv = 0.0;
+        RayD ray;
+        if (valid) {
+            const GiJob &job = gp.jobs[job_index];
+            const d3 P = mk3(job.P[0], job.P[1], job.P[2]), n = mk3(job.n[0], job.n[1], job.n[2]);
+            double u1, u2;
+            rng_pair(wl.seed, job.pixel, job.sample, path_child(job.path, SLOT_GI + slot), &u1, &u2);
+            ray.d = sample_direction(SAMPLE_HEMISPHERE, n, 0.0, u1, u2);
+            ray.o = P + ray.d * BIAS;  // :115
+            closest_hit<COUNT>(sc, top_nodes, stack, ray, ctr, n_nodes, n_prims, &hit_id, &hit_t, &hit_bu, &hit_bv);
+        }
+        wave_rays += static_cast<uint32_t>(__popcll(__ballot(valid)));
+        // ---- classify (get_illumination :492-520)
+        const bool hit = valid && hit_id != RT_NO_HIT;
+        const bool occluded = hit && hit_t <= sc.opts.max_occlusion_distance;
+        uint32_t pf = 0;
+        if (hit) pf = sc.prim_flags[hit_id];
+        const bool terminal = hit && ((pf & PRIM_ILLUM_TERMINAL) || !next_real);
+        const bool wants_node = hit && !terminal;
+        const bool special = wants_node || (terminal && (pf & PRIM_EMISSIVE));
+        const unsigned long long m_unocc = __ballot(valid && !occluded), m_special = __ballot(special), m_node = __ballot(wants_node);
+        const unsigned long long job_mask = (G == 64u ? ~0ull : ((1ull << G) - 1ull)) << (jl * G);  // this lane's job's lanes
+        const unsigned long long below = (1ull << lane) - 1ull;
+        // wave-wide allocation of specials and nodes (every lane of the wave reaches this)
+        const uint32_t tot_special = static_cast<uint32_t>(__popcll(m_special)), tot_node = static_cast<uint32_t>(__popcll(m_node));
+        unsigned long long base_special = 0, base_node = 0;
+        if (lane == 0) {
+            if (tot_special) base_special = atomicAdd(&ctr->special_alloc, static_cast<unsigned long long>(tot_special));
+            if (tot_node) base_node = atomicAdd(&ctr->node_alloc, static_cast<unsigned long long>(tot_node));
+        }
+        base_special = __shfl(base_special, 0, 64);
+        base_node = __shfl(base_node, 0, 64);
+        if (base_special + tot_special > shards.special_cap || base_node + tot_node > shards.node_cap) {
+            if (lane == 0) atomicOr(&ctr->overflow, 1u);
+            break;  // wave-uniform: the batch is re-run smaller
+        }
+        uint32_t node_index = 0;
+        if (wants_node) {
+            node_index = c.node_off + static_cast<uint32_t>(base_node) + static_cast<uint32_t>(__popcll(m_node & below));
+            const GiJob &job = gp.jobs[job_index];  // path and root are not kept across the traversal: read again
+            store_ray(np, node_index, ray.o, ray.d);
+            np.path[node_index] = path_child(job.path, SLOT_GI + slot);
+            np.root[node_index] = job.root;
+            np.meta[node_index] = level | META_ILLUM | META_TRACED;
+            np.prim[node_index] = hit_id;
+            np.t[node_index] = hit_t;
+            np.bu[node_index] = hit_bu;
+            np.bv[node_index] = hit_bv;
+        }
+        wave_nodes += tot_node;
+        const uint32_t special_off = c.special_off + static_cast<uint32_t>(base_special);
+        if (special)
+            gp.specials[special_off + static_cast<uint32_t>(__popcll(m_special & below))] =
+                GiSpecial{slot | (wants_node ? 0x80000000u : 0u), wants_node ? node_index : hit_id};
+        if (valid && slot == 0) {  // the job's results
+            GiJob &job = gp.jobs[job_index];
+            job.unoccluded = static_cast<uint32_t>(__popcll(m_unocc & job_mask));
+            job.n_special = static_cast<uint32_t>(__popcll(m_special & job_mask));
+            job.first_special = special_off + static_cast<uint32_t>(__popcll(m_special & ((1ull << (jl * G)) - 1ull)));
+        }
+    }
+    // statistics: rays traced here, nodes made here (one atomic pair per wave)
+    if (lane == 0 && wave_rays) {
+        atomicAdd(&ctr->gi_rays, static_cast<unsigned long long>(wave_rays));
+        if (wave_nodes) atomicAdd(&ctr->gi_materialised, static_cast<unsigned long long>(wave_nodes));
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->nodes_visited_closest, n_nodes & ((1ull << 40) - 1ull));
+        atomicAdd(&ctr->prims_tested_closest, n_prims & ((1ull << 40) - 1ull));
     }
 }
 
@@ -832,7 +984,7 @@ __device__ __forceinline__ uint32_t wave_owner(const uint32_t *incl, uint32_t j)
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, Counters *ctrs,
+__global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, GiPool gp, Counters *ctrs,
                                                  Shards shards, uint32_t level) {
     __shared__ ExpandLds L;
     __shared__ LiveMap map;
@@ -840,6 +992,7 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
     Counters *ctr = c.ctr;
     const uint32_t n_groups = live_map_build(map, ctrs, shards, level, true, true);
     const bool next_real = level + 1 < sc.opts.max_depth;
+    const bool gi_in_place = gi_rays(sc, level) <= GI_MAX_INPLACE;  // the level's GI rays get jobs (k_trace_gi), not nodes
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
     const uint32_t child_depth = level + 1;
     const uint32_t wave_stride = gridDim.x * (BLOCK / 64);
@@ -847,8 +1000,9 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
         const uint32_t node = live_map_node(map, shards, np.live, g, lane);
         const bool valid = node != 0xFFFFFFFFu;
         const uint32_t idx = valid ? node : 0u;
-        uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0, phong_flag = 0;
+        uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0, phong_flag = 0, nJ = 0;
         uint32_t prim = RT_NO_HIT, meta = 0;
+        d3 job_P = mk3(0.0, 0.0, 0.0), job_n = mk3(0.0, 0.0, 0.0);
         if (valid) {
             meta = np.meta[idx];
             prim = np.prim[idx];
@@ -882,6 +1036,12 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
                 }
             }
             if (!next_real) nR = nT = nG = 0;
+            if (gi_in_place && nG) {  // one job instead of nG child nodes
+                nJ = 1;
+                nG = 0;
+                job_P = s.P;
+                job_n = s.n;
+            }
             if (cast_shadows) {
                 uint32_t bit = 0;
                 for (uint32_t li = 0; li < sc.n_lights; ++li) {
@@ -915,7 +1075,7 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
                 L.ty[tid] = refr_dir.y;
                 L.tz[tid] = refr_dir.z;
             }
-            if (nR + nT + nG) {
+            if (nR + nT + nG + nJ) {
                 const uint32_t root = np.root[idx];
                 uint32_t px, py, sample;
                 item_to_pixel(wl, root, &px, &py, &sample);
@@ -939,9 +1099,12 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
         uint32_t wave_nodes, wave_shadows;
         const uint64_t child64 = wave_alloc(&ctr->node_alloc, total, &wave_nodes);
         const uint64_t shadow64 = wave_alloc(&ctr->shadow_alloc, nS, &wave_shadows);
+        uint32_t wave_jobs = 0;
+        uint64_t job64 = 0;
+        if (gi_in_place && next_real) job64 = wave_alloc(&ctr->job_alloc, nJ, &wave_jobs);  // wave-uniform condition
         // shard-local positions; wave-uniform overflow test (first lane's base + wave total)
-        const uint64_t node_local = __shfl(child64, 0, 64), shadow_local = __shfl(shadow64, 0, 64);
-        if (node_local + wave_nodes > shards.node_cap || shadow_local + wave_shadows > shards.shadow_cap) {
+        const uint64_t node_local = __shfl(child64, 0, 64), shadow_local = __shfl(shadow64, 0, 64), job_local = __shfl(job64, 0, 64);
+        if (node_local + wave_nodes > shards.node_cap || shadow_local + wave_shadows > shards.shadow_cap || job_local + wave_jobs > shards.job_cap) {
             if (lane == 0) atomicOr(&ctr->overflow, 1u);
             return;  // the shard is dead for this batch (wave-uniform exit)
         }
@@ -952,7 +1115,22 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
         L.incl_nodes[tid] = first_child - node_base + total;
         L.incl_shadows[tid] = first_shadow - shadow_base + nS;
         if (valid) {
-            np.xinfo[idx] = ExpandInfo{first_child, first_shadow, nR | (nT << 16) | (nG << 17), mask};
+            np.xinfo[idx] = ExpandInfo{first_child, first_shadow, nR | (nT << 16) | (nJ ? 0x80000000u : (nG << 17)), mask};
+        }
+        if (nJ) {  // the job: what k_trace_gi needs to draw this node's GI rays
+            const uint32_t ji = c.job_off + static_cast<uint32_t>(job64);
+            np.gi_job[idx] = ji;
+            GiJob job;
+            job.P[0] = job_P.x; job.P[1] = job_P.y; job.P[2] = job_P.z;
+            job.n[0] = job_n.x; job.n[1] = job_n.y; job.n[2] = job_n.z;
+            job.path = L.path[tid];
+            job.root = L.root[tid];
+            job.pixel = L.pixel[tid];
+            job.sample = L.sample[tid];
+            job.unoccluded = 0;
+            job.n_special = 0;
+            job.first_special = 0;
+            gp.jobs[ji] = job;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // phase A's LDS stores -> phase B's reads (same wave)
 
@@ -1031,7 +1209,7 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
 // few multiplies) and colour nodes (the full shading; register heavy), so that the
 // illumination nodes do not run at the colour path's two waves per SIMD.
 template <bool ILLUM>
-__global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, Counters *ctrs, Shards shards,
+__global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, GiPool gp, Counters *ctrs, Shards shards,
                                                   uint32_t level, uint32_t aov) {
     __shared__ LiveMap map;
     const uint32_t n_groups = live_map_build(map, ctrs, shards, level, !ILLUM, ILLUM);
@@ -1061,7 +1239,8 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES)
             // next level is cut off).  Their result words are read four at a time (aligned 16-byte loads over the
             // block of children); bit 1 of a word says whether its RGB is non-zero (4 of 5 are black: nothing more to
             // load), bit 0 "occluded".  Each class is summed in slot order, as the reference's loops do.
-            const uint32_t nR = counts & 0xFFFFu, nT = (counts >> 16) & 1u, nG = (counts >> 17) & 0x3FFFu;
+            const bool gi_job = !ILLUM && (counts >> 31) != 0u;  // this node's GI rays were traced in place
+            const uint32_t nR = counts & 0xFFFFu, nT = (counts >> 16) & 1u, nG = gi_job ? 0u : (counts >> 17) & 0x3FFFu;
             const bool clamp_each = !ILLUM && m.kind == RT_MAT_PHYSICAL;  // :380 adds clamped colours; :299 and :196 raw ones
             d3 refl_sum = mk3(0.0, 0.0, 0.0), refr_rgb = mk3(0.0, 0.0, 0.0), gi_sum = mk3(0.0, 0.0, 0.0);
             uint32_t unoccluded = 0;
@@ -1085,6 +1264,21 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES)
                             if (w[j] & 2u) gi_sum = gi_sum + rgb;
                             if (!(w[j] & 1u)) unoccluded++;
                         }
+                    }
+                }
+            }
+
+            if (gi_job) {  // compute_global_illumination's sums from the job: the non-zero terms in slot order (:121), the count (:123-125)
+                const GiJob &job = gp.jobs[np.gi_job[idx]];
+                unoccluded = job.unoccluded;
+                const uint32_t ns = job.n_special, fs = job.first_special;
+                for (uint32_t q = 0; q < ns; ++q) {
+                    const GiSpecial sp1 = gp.specials[fs + q];
+                    if (sp1.slot_kind >> 31) {  // a node of its own, resolved one level down
+                        if (np.prim[sp1.id] & 2u) gi_sum = gi_sum + mk3(np.t[sp1.id], np.bu[sp1.id], np.bv[sp1.id]);
+                    } else {                    // terminal hit on an emissive surface: get_emissive_* = the material's colour
+                        const rt_material &em = sc.materials[sc.shade_prims[sp1.id].material];
+                        gi_sum = gi_sum + mk3(em.emissive[0], em.emissive[1], em.emissive[2]);
                     }
                 }
             }
