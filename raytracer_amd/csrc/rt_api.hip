@@ -591,7 +591,7 @@ Shards plan_shards(const RenderCtx &c, uint64_t n, uint32_t ns) {
 uint32_t stack_entries(const rt_scene *s) { return static_cast<uint32_t>(s->bvh_depth + 2); }
 uint32_t stack_lds_bytes(const rt_scene *s) {
     static const uint32_t extra = std::getenv("MI355RT_EXTRA_LDS") ? std::atoi(std::getenv("MI355RT_EXTRA_LDS")) : 0;  // occupancy experiments
-    return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + s->dev.n_top_nodes * static_cast<uint32_t>(sizeof(BvhNode)) + extra;
+    return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + (s->dev.n_top_nodes + s->dev.n_top_s) * static_cast<uint32_t>(sizeof(BvhNode)) + extra;
 }
 
 Shards single_shard(const RenderCtx &c) {
@@ -897,11 +897,9 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         }
     }
     lap("BVH build");
-    std::vector<LeafPrim> leaf(bvh.order.size());
-    parallel_for(bvh.order.size(), [&](size_t j0, size_t j1) {
-    for (size_t j = j0; j < j1; ++j) {
-        const uint32_t b = bvh.order[j], pid = bounded_ids[b];
-        LeafPrim &lp = leaf[j];
+    auto leaf_record = [&](uint32_t b) {  // b: index into bounded_ids / boxes
+        const uint32_t pid = bounded_ids[b];
+        LeafPrim lp;
         std::memset(&lp, 0, sizeof(lp));
         for (int k = 0; k < 3; ++k) {  // BoundingVolume::intersect, bounds.rs:116-121
             lp.center[k] = (boxes[b].mn[k] + boxes[b].mx[k]) * 0.5;
@@ -920,11 +918,49 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         }
         lp.prim_id = pid;
         lp.meta = sh.type | (d->materials[sh.material].side << 2) | (sh.xf << 4);
-    }
+        return lp;
+    };
+    std::vector<LeafPrim> leaf(bvh.order.size());
+    parallel_for(bvh.order.size(), [&](size_t j0, size_t j1) {
+        for (size_t j = j0; j < j1; ++j) leaf[j] = leaf_record(bvh.order[j]);
     });
+    // get_emissive_phong (:135-167) adds a child only if reflectivity > 0; get_emissive_physical (:263-337)
+    // only if max_reflected_rays > 0 or opacity < 1: otherwise an illumination ray's result is the emissive colour
+    std::vector<uint32_t> prim_flags(d->n_prims);
+    uint32_t n_special = 0;
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const rt_material &m = d->materials[shade[i].material];
+        const bool terminal = m.kind == RT_MAT_PHONG ? !(m.reflectivity > 0.0) : (o.max_reflected_rays == 0 && !(m.opacity < 1.0));
+        const bool emissive = m.emissive[0] != 0.0 || m.emissive[1] != 0.0 || m.emissive[2] != 0.0;
+        prim_flags[i] = (terminal ? PRIM_ILLUM_TERMINAL : 0u) | (emissive ? PRIM_EMISSIVE : 0u);
+        if (!terminal || emissive) n_special++;
+    }
+    // ---- two-phase GI queries (k_trace_gi): worth it when the special primitives are few.  Their tree is built on the
+    // host in the main tree's quantisation frame, so one CullRay serves both.  MI355RT_GI_TWO_PHASE=0|1 forces the choice.
+    BvhBuildResult bvh_s;
+    std::vector<LeafPrim> leaf_s;
+    bool two_phase = static_cast<uint64_t>(n_special) * 8u <= d->n_prims;
+    if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) two_phase = std::strcmp(want, "0") != 0;
+    if (two_phase && n_special > 0) {
+        std::vector<uint32_t> sub;  // indices into bounded_ids
+        for (size_t b = 0; b < n_bounded; ++b) {
+            const uint32_t f = prim_flags[bounded_ids[b]];
+            if (!(f & PRIM_ILLUM_TERMINAL) || (f & PRIM_EMISSIVE)) sub.push_back(static_cast<uint32_t>(b));
+        }
+        std::vector<Aabb> sub_boxes(sub.size());
+        std::vector<uint32_t> sub_group(sub.size());
+        for (size_t j = 0; j < sub.size(); ++j) {
+            sub_boxes[j] = cull_boxes[sub[j]];
+            sub_group[j] = leaf_group[sub[j]];
+        }
+        bvh_s = build_bvh(sub_boxes, &sub_group, 0, bvh.q_origin, bvh.q_scale);
+        leaf_s.resize(bvh_s.order.size());
+        for (size_t j = 0; j < leaf_s.size(); ++j) leaf_s[j] = leaf_record(sub[bvh_s.order[j]]);
+    }
+    lap("special primitives");
     sc->n_nodes = n_built_nodes;
     sc->n_leaves = bvh.n_leaves;
-    sc->bvh_depth = bvh.max_depth;
+    sc->bvh_depth = std::max(bvh.max_depth, bvh_s.max_depth);
     lap("leaf records");
 
     // ---- upload
@@ -936,11 +972,15 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     dev.root_ref = bvh.root_ref;
     {   // top of the tree kept in LDS by the traversal kernels: as many nodes as fit next to the per-lane stacks
         // without costing a block per CU (four 256-thread blocks share 160 KB), at most 512 (16 KB)
-        const uint32_t stack_bytes = (bvh.max_depth + 2u) * BLOCK * static_cast<uint32_t>(sizeof(uint32_t));
+        const uint32_t stack_bytes = (static_cast<uint32_t>(sc->bvh_depth) + 2u) * BLOCK * static_cast<uint32_t>(sizeof(uint32_t));
         const uint32_t budget = 40u * 1024u - 2048u;  // per block; 2 KB for the kernels' static LDS (work map, live-list masks)
         const uint32_t fit = stack_bytes < budget ? (budget - stack_bytes) / static_cast<uint32_t>(sizeof(BvhNode)) : 0u;
         dev.n_top_nodes = static_cast<uint32_t>(std::min<size_t>(n_built_nodes, std::min(fit, 512u)));
+        dev.n_top_s = static_cast<uint32_t>(std::min<size_t>(bvh_s.nodes.size(), std::min(fit - dev.n_top_nodes, 64u)));
     }
+    dev.root_ref_s = bvh_s.root_ref;
+    dev.n_special = n_special;
+    dev.gi_two_phase = two_phase ? 1u : 0u;
     dev.n_planes = static_cast<uint32_t>(planes.size());
     dev.n_bounded = static_cast<uint32_t>(bounded_ids.size());
     dev.n_prims = d->n_prims;
@@ -982,15 +1022,8 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     else if ((rc = upload(st, bvh.nodes, &dev.nodes, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, leaf, &dev.leaf_prims, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, planes, &dev.planes, sc->allocs, bytes))) return rc;
-    // get_emissive_phong (:135-167) adds a child only if reflectivity > 0; get_emissive_physical (:263-337)
-    // only if max_reflected_rays > 0 or opacity < 1: otherwise an illumination ray's result is the emissive colour
-    std::vector<uint32_t> prim_flags(d->n_prims);
-    for (uint32_t i = 0; i < d->n_prims; ++i) {
-        const rt_material &m = d->materials[shade[i].material];
-        const bool terminal = m.kind == RT_MAT_PHONG ? !(m.reflectivity > 0.0) : (o.max_reflected_rays == 0 && !(m.opacity < 1.0));
-        const bool emissive = m.emissive[0] != 0.0 || m.emissive[1] != 0.0 || m.emissive[2] != 0.0;
-        prim_flags[i] = (terminal ? PRIM_ILLUM_TERMINAL : 0u) | (emissive ? PRIM_EMISSIVE : 0u);
-    }
+    if ((rc = upload(st, bvh_s.nodes, &dev.nodes_s, sc->allocs, bytes))) return rc;
+    if ((rc = upload(st, leaf_s, &dev.leaf_prims_s, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, shade, &dev.shade_prims, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, prim_flags, &dev.prim_flags, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, d->inv_world, 12ull * d->n_transforms, &dev.inv_world, sc->allocs, bytes))) return rc;

@@ -330,7 +330,8 @@ struct Builder {
 
 }  // namespace
 
-BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint32_t> *leaf_group, uint32_t max_threads) {
+BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint32_t> *leaf_group, uint32_t max_threads,
+                         const float *frame_origin, const float *frame_scale) {
     Builder b(boxes);
     b.leaf_group = leaf_group;
     b.max_threads = max_threads;
@@ -359,6 +360,12 @@ BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint3
         if (!(extent > 0.0) || !std::isfinite(extent)) extent = 1.0;
         b.out.q_scale[k] = round_up(extent / 65535.0 * (1.0 + 1e-6));
         scale[k] = static_cast<double>(b.out.q_scale[k]);
+        if (frame_origin && frame_scale) {  // the caller's frame: the boxes must lie inside it (a subset of the tree that defined it)
+            b.out.q_origin[k] = frame_origin[k];
+            b.out.q_scale[k] = frame_scale[k];
+            origin[k] = static_cast<double>(frame_origin[k]);
+            scale[k] = static_cast<double>(frame_scale[k]);
+        }
     }
     // origin + q * scale <= x for minima (>= for maxima), in exact arithmetic on the stored f32 frame
     auto q_down = [&](double x, int k) -> uint16_t {

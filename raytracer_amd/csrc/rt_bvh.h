@@ -30,7 +30,10 @@ struct BvhBuildResult {
 constexpr uint32_t NO_LEAF_GROUP = 0xFFFFFFFFu;
 // max_threads: workers for the subtree jobs of a large scene (0 = the host's cores, at most 16); the tree does not
 // depend on it.
-BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint32_t> *leaf_group = nullptr, uint32_t max_threads = 0);
+// frame_origin / frame_scale (optional, 3 floats each): quantise the node boxes in this frame instead of the tree's own
+// root box (a tree over a subset of another tree's primitives, traversed with the same CullRay).
+BvhBuildResult build_bvh(const std::vector<Aabb> &boxes, const std::vector<uint32_t> *leaf_group = nullptr, uint32_t max_threads = 0,
+                         const float *frame_origin = nullptr, const float *frame_scale = nullptr);
 
 inline uint32_t make_leaf_ref(uint32_t first, uint32_t count) {
     return LEAF_FLAG | ((count - 1u) << 28) | first;

@@ -110,6 +110,14 @@ struct SceneDev {
     double scene_scale;   // max |coordinate| of the root box
     float q_origin[3];    // node boxes: coordinate = q_origin + q * q_scale (q = 0..65535)
     float q_scale[3];
+    // two-phase GI queries (k_trace_gi): the special primitives -- emissive, or an illumination hit needs child rays
+    // (PRIM_* flags) -- have a tree of their own, in the frame of the main one; used when they are few
+    const BvhNode *nodes_s;
+    const LeafPrim *leaf_prims_s;
+    uint32_t root_ref_s;    // 0xFFFFFFFF: no bounded special primitive
+    uint32_t n_top_s;       // nodes of that tree kept in LDS behind the main tree's
+    uint32_t n_special;     // special primitives, planes included
+    uint32_t gi_two_phase;  // k_trace_gi: closest special hit + any-hit instead of one closest-hit query
     // shading
     const ShadePrim *shade_prims;
     const uint32_t *prim_flags;  // primitive-ID order, PRIM_* bits

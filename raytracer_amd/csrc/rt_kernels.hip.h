@@ -209,6 +209,7 @@ __device__ __forceinline__ uint32_t ipow(uint32_t b, uint32_t e) {
     return r;
 }
 // raytracing_scene.rs:104-105 and :279-280 / :363-364
+__device__ __forceinline__ bool is_special(uint32_t prim_flags) { return (prim_flags & PRIM_EMISSIVE) || !(prim_flags & PRIM_ILLUM_TERMINAL); }
 __device__ __forceinline__ uint32_t gi_rays(const SceneDev &sc, uint32_t depth) {
     uint32_t n = sc.opts.max_illumination_rays / ipow(4u, depth);
     return n < 1u ? 1u : n;
@@ -540,18 +541,35 @@ __device__ __forceinline__ const uint4 *stage_top_nodes(const SceneDev &sc, uint
     uint4 *top = reinterpret_cast<uint4 *>(stack_lds + stack_entries * BLOCK);
     const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes);
     for (uint32_t i = threadIdx.x; i < sc.n_top_nodes * 2u; i += BLOCK) top[i] = src[i];
+    const uint4 *src_s = reinterpret_cast<const uint4 *>(sc.nodes_s);  // the tree of the special primitives, behind it
+    for (uint32_t i = threadIdx.x; i < sc.n_top_s * 2u; i += BLOCK) top[sc.n_top_nodes * 2u + i] = src_s[i];
     __syncthreads();
     return top;
 }
 
+// One of the scene's two trees: all bounded primitives, or the special ones only (SceneDev::nodes_s).
+struct TreeView {
+    const BvhNode *nodes;
+    const LeafPrim *leaf_prims;
+    const uint4 *top;  // LDS copy of nodes [0, n_top)
+    uint32_t n_top;
+    uint32_t root_ref;
+};
+__device__ __forceinline__ TreeView main_tree(const SceneDev &sc, const uint4 *top_nodes) {
+    return TreeView{sc.nodes, sc.leaf_prims, top_nodes, sc.n_top_nodes, sc.root_ref};
+}
+__device__ __forceinline__ TreeView special_tree(const SceneDev &sc, const uint4 *top_nodes) {
+    return TreeView{sc.nodes_s, sc.leaf_prims_s, top_nodes + 2u * sc.n_top_nodes, sc.n_top_s, sc.root_ref_s};
+}
+
 // Descend from `cur` through interior nodes until a leaf ref or the sentinel.
 template <bool COUNT>
-__device__ __forceinline__ uint32_t descend(const SceneDev &sc, const uint4 *top_nodes, const CullRay &cr, float limit, uint32_t cur,
+__device__ __forceinline__ uint32_t descend(const TreeView &tv, const CullRay &cr, float limit, uint32_t cur,
                                             uint32_t *stack, uint32_t &sp, unsigned long long &n_nodes) {
     while (!(cur & LEAF_FLAG) && cur != STACK_SENTINEL) {
         // the 32-byte node (lmin lmax rmin | rmax left right) through a generic pointer: one pair of 16-byte loads
         // serves the lanes whose node is in LDS and those whose node is in memory
-        const uint4 *nd = cur < sc.n_top_nodes ? top_nodes + 2u * cur : reinterpret_cast<const uint4 *>(sc.nodes + cur);
+        const uint4 *nd = cur < tv.n_top ? tv.top + 2u * cur : reinterpret_cast<const uint4 *>(tv.nodes + cur);
         const uint4 w0 = nd[0], w1 = nd[1];
         if (COUNT) {  // low 40 bits: lane-level visits; high bits: wave-level visits (counted by the first active lane)
             n_nodes++;
@@ -582,17 +600,22 @@ __device__ __forceinline__ uint32_t descend(const SceneDev &sc, const uint4 *top
 
 // KdTreeAccelerator::raycast (bounds.rs:302-308) for one ray, in the traversal-order independent form: the unbounded
 // objects, then the BVH; minimum of (t, bounded?, primitive id).  Shared by k_trace_closest and k_trace_gi.
-template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const SceneDev &sc, const uint4 *top_nodes, uint32_t *stack, const RayD &ray, Counters *ctr,
+// SPECIAL: only the special primitives (PRIM_* flags: emissive, or an illumination hit needs child rays) -- the planes
+// among them and the tree `tv` of the bounded ones; `key_out` then gets the rest of the winner's ordering key
+// (bit 31: bounded; low bits: plane list index / primitive id).  `shared_cr`: the ray's CullRay if the caller has it.
+template <bool COUNT, bool SPECIAL>
+__device__ __forceinline__ void closest_hit(const SceneDev &sc, const TreeView &tv, uint32_t *stack, const RayD &ray, Counters *ctr,
                                             unsigned long long &n_nodes, unsigned long long &n_prims, uint32_t *id_out, double *t_out,
-                                            double *bu_out, double *bv_out) {
+                                            double *bu_out, double *bv_out, const CullRay *shared_cr = nullptr, uint32_t *key_out = nullptr) {
     double best_t = __builtin_inf();
     uint32_t best_id = RT_NO_HIT;
     double best_bu = 0.0, best_bv = 0.0;
     bool best_bounded = false;
+    uint32_t best_plane = 0;
 
     for (uint32_t p = 0; p < sc.n_planes; ++p) {  // unbounded objects first (bounds.rs:303-305)
         const PlanePrim pl = sc.planes[p];
+        if (SPECIAL && !is_special(sc.prim_flags[pl.prim_id])) continue;
         const double *inv = sc.inv_world + 12ull * (pl.meta >> 4);
         RayD orr;
         orr.o = xf_point(inv, ray.o);
@@ -604,23 +627,24 @@ __device__ __forceinline__ void closest_hit(const SceneDev &sc, const uint4 *top
             (best_id == RT_NO_HIT || h.t < best_t)) {
             best_t = h.t;
             best_id = pl.prim_id;
+            best_plane = p;
         }
     }
 
-    if (sc.root_ref != 0xFFFFFFFFu) {
-        const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
+    if (tv.root_ref != 0xFFFFFFFFu) {
+        const CullRay cr = shared_cr ? *shared_cr : make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
         ObjRayCache cache;
         cache.xf = 0xFFFFFFFFu;
         stack[0] = STACK_SENTINEL;
         uint32_t sp = 1;
-        uint32_t cur = sc.root_ref;
+        uint32_t cur = tv.root_ref;
         while (true) {
-            cur = descend<COUNT>(sc, top_nodes, cr, cull_limit_f32(cull_limit(best_t)), cur, stack, sp, n_nodes);
+            cur = descend<COUNT>(tv, cr, cull_limit_f32(cull_limit(best_t)), cur, stack, sp, n_nodes);
             if (cur == STACK_SENTINEL) break;
             const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
             if (COUNT && (threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(__ballot(true)) - 1)) n_prims += 1ull << 40;  // wave-level leaf round
             for (uint32_t k = 0; k < n; ++k) {
-                const LeafPrim *lp = sc.leaf_prims + first + k;
+                const LeafPrim *lp = tv.leaf_prims + first + k;
                 HitRec h;
                 if (COUNT) n_prims++;
                 uint32_t exact_box = 0, pid, ty = 0;
@@ -653,6 +677,61 @@ __device__ __forceinline__ void closest_hit(const SceneDev &sc, const uint4 *top
     *t_out = best_t;
     *bu_out = best_bu;
     *bv_out = best_bv;
+    if (key_out) *key_out = best_bounded ? (0x80000000u | best_id) : best_plane;
+}
+
+// The second half of a two-phase GI query (k_trace_gi): given the closest SPECIAL hit S of the ray (s_exists, s_t,
+// s_key as closest_hit<., true> returns them), decide what the closest hit over ALL primitives would be without
+// finding it: any primitive that precedes S in the order (t, bounded?, id) makes the closest hit a plain one, and of
+// a plain hit get_illumination (:492-520) uses nothing but `distance <= max_occlusion_distance` (D).  So the search
+// stops at the first preceding hit within D, and once a preceding hit beyond D is known only hits within D matter.
+// A special primitive met again here never precedes S (S is the first of them; the same record gives the same t).
+// Returns bit 0: a preceding hit exists (the closest hit is plain); bit 1: the closest hit lies within D.
+template <bool COUNT>
+__device__ __forceinline__ uint32_t any_hit_before(const SceneDev &sc, const TreeView &tv, uint32_t *stack, const RayD &ray, const CullRay &cr,
+                                                   unsigned long long &n_nodes, unsigned long long &n_prims, bool s_exists, double s_t,
+                                                   uint32_t s_key, double D) {
+    bool found = false, within = false;
+    double limit = s_exists ? s_t : D;  // hits beyond it change nothing
+    for (uint32_t p = 0; p < sc.n_planes && !within; ++p) {
+        const PlanePrim pl = sc.planes[p];
+        const double *inv = sc.inv_world + 12ull * (pl.meta >> 4);
+        RayD orr;
+        orr.o = xf_point(inv, ray.o);
+        orr.d = xf_vector(inv, ray.d);
+        HitRec h;
+        if (COUNT) n_prims++;
+        if (!hit_plane(mk3(pl.normal[0], pl.normal[1], pl.normal[2]), (pl.meta >> 2) & 3u, false, orr, false, 0.0, &h)) continue;
+        if (s_exists && !(h.t < s_t || (h.t == s_t && p < s_key))) continue;  // an unbounded S has key = its list index; a bounded one 2^31 + id
+        if (h.t <= D) within = true;
+        if (s_exists || h.t <= D) found = true;
+        if (!within) limit = D;
+    }
+    if (!within && tv.root_ref != 0xFFFFFFFFu) {
+        ObjRayCache cache;
+        cache.xf = 0xFFFFFFFFu;
+        stack[0] = STACK_SENTINEL;
+        uint32_t sp = 1;
+        uint32_t cur = tv.root_ref;
+        while (true) {
+            cur = descend<COUNT>(tv, cr, cull_limit_f32(cull_limit(limit)), cur, stack, sp, n_nodes);
+            if (cur == STACK_SENTINEL) break;
+            const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t k = 0; k < n && !within; ++k) {
+                HitRec h;
+                if (COUNT) n_prims++;
+                uint32_t pid;
+                if (!test_leaf_prim<false>(sc, tv.leaf_prims + first + k, ray, cache, 0.0, &h, &pid)) continue;
+                if (s_exists && !(h.t < s_t || (h.t == s_t && (0x80000000u | pid) < s_key))) continue;
+                if (h.t <= D) within = true;
+                if (s_exists || h.t <= D) found = true;
+                if (!within) limit = D;
+            }
+            if (within) break;
+            cur = stack[(--sp) * BLOCK];
+        }
+    }
+    return (found ? 1u : 0u) | (within ? 2u : 0u);
 }
 
 // KdTreeAccelerator::raycast semantics, traversal-order independent form
@@ -688,7 +767,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
         load_ray(np, idx, &ray.o, &ray.d);
         double best_t, best_bu, best_bv;
         uint32_t best_id;
-        closest_hit<COUNT>(sc, top_nodes, stack, ray, ctr, n_nodes, n_prims, &best_id, &best_t, &best_bu, &best_bv);
+        closest_hit<COUNT, false>(sc, main_tree(sc, top_nodes), stack, ray, ctr, n_nodes, n_prims, &best_id, &best_t, &best_bu, &best_bv);
         if (FINALIZE) {
             bool done = best_id == RT_NO_HIT;
             uint32_t flag = 0;
@@ -792,7 +871,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_gi(SceneDev sc, Wo
         const uint32_t jl = lane / G, slot = lane - jl * G;
         const bool valid = lane < used && jl < jobs_here;
         const uint32_t job_index = map.base[k] + first_job + (valid ? jl : 0u);
-        uint32_t hit_id = RT_NO_HIT;
+        uint32_t hit_id = RT_NO_HIT, plain = 0;  // plain: any_hit_before's answer when the closest hit is a plain primitive
         double hit_t = 0.0, hit_bu = 0.0, hit_bv = 0.0;
         RayD ray;
         if (valid) {
@@ -802,12 +881,20 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_gi(SceneDev sc, Wo
             rng_pair(wl.seed, job.pixel, job.sample, path_child(job.path, SLOT_GI + slot), &u1, &u2);
             ray.d = sample_direction(SAMPLE_HEMISPHERE, n, 0.0, u1, u2);
             ray.o = P + ray.d * BIAS;  // :115
-            closest_hit<COUNT>(sc, top_nodes, stack, ray, ctr, n_nodes, n_prims, &hit_id, &hit_t, &hit_bu, &hit_bv);
+            if (sc.gi_two_phase) {  // closest special hit, then: does anything precede it / lie within the occlusion distance?
+                const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
+                uint32_t s_key = 0;
+                if (sc.n_special) closest_hit<COUNT, true>(sc, special_tree(sc, top_nodes), stack, ray, ctr, n_nodes, n_prims, &hit_id, &hit_t, &hit_bu, &hit_bv, &cr, &s_key);
+                plain = any_hit_before<COUNT>(sc, main_tree(sc, top_nodes), stack, ray, cr, n_nodes, n_prims, hit_id != RT_NO_HIT, hit_t, s_key,
+                                              sc.opts.max_occlusion_distance);
+            } else {
+                closest_hit<COUNT, false>(sc, main_tree(sc, top_nodes), stack, ray, ctr, n_nodes, n_prims, &hit_id, &hit_t, &hit_bu, &hit_bv);
+            }
         }
         wave_rays += static_cast<uint32_t>(__popcll(__ballot(valid)));
         // ---- classify (get_illumination :492-520)
-        const bool hit = valid && hit_id != RT_NO_HIT;
-        const bool occluded = hit && hit_t <= sc.opts.max_occlusion_distance;
+        const bool hit = valid && hit_id != RT_NO_HIT && !(plain & 1u);
+        const bool occluded = (plain & 1u) ? (plain & 2u) != 0 : hit && hit_t <= sc.opts.max_occlusion_distance;
         uint32_t pf = 0;
         if (hit) pf = sc.prim_flags[hit_id];
         const bool terminal = hit && ((pf & PRIM_ILLUM_TERMINAL) || !next_real);
@@ -922,7 +1009,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
             uint32_t sp = 1;
             uint32_t cur = sc.root_ref;
             while (true) {
-                cur = descend<COUNT>(sc, top_nodes, cr, limit, cur, stack, sp, n_nodes);
+                cur = descend<COUNT>(main_tree(sc, top_nodes), cr, limit, cur, stack, sp, n_nodes);
                 if (cur == STACK_SENTINEL) break;
                 const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
                 for (uint32_t k = 0; k < n && !occluded; ++k) {
