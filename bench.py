@@ -202,8 +202,8 @@ def main():
         prim_types = scene.prim_types()
         tri_share = float((prim_types == _abi.RT_PRIM_TRIANGLE).mean()) if len(prim_types) else 0.0
         n_steps = max(1, len(timed_stats))
-        ms = {k: sum(getattr(s, "ms_" + k) for s in timed_stats) / n_steps for k in ("raygen", "closest", "shadow", "expand", "resolve", "accum")}
-        launches = {"closest": sum(s.launches_closest for s in timed_stats) / n_steps, "shadow": sum(s.launches_shadow for s in timed_stats) / n_steps}
+        ms = {k: sum(getattr(s, "ms_" + k) for s in timed_stats) / n_steps for k in ("raygen", "closest", "gi", "shadow", "expand", "resolve", "accum")}
+        launches = {k: sum(getattr(s, "launches_" + k) for s in timed_stats) / n_steps for k in ("closest", "gi", "shadow")}
         nodes_c = work.nodes_visited_closest / max(1, work.closest_rays)
         prims_c = work.prims_tested_closest / max(1, work.closest_rays)
         nodes_s = work.nodes_visited_shadow / max(1, work.shadow_rays)
@@ -211,10 +211,13 @@ def main():
         bytes_c = algorithmic_bytes("closest", nodes_c, prims_c * tri_share, prims_c * (1 - tri_share))
         bytes_s = algorithmic_bytes("shadow", nodes_s, prims_s * tri_share, prims_s * (1 - tri_share))
         dominant = max(ms, key=ms.get)
-        kern = "closest" if dominant not in ("closest", "shadow") else dominant
-        k_rays = work.closest_rays if kern == "closest" else work.shadow_rays
-        k_bytes = bytes_c if kern == "closest" else bytes_s          # SURVEY 8(d) incl. the geometry term
-        k_stream = 224.0 if kern == "closest" else 136.0             # SURVEY 8(d) wavefront records only: what MUST cross HBM
+        # the three traversal kernels: k_trace_closest (rays stored as nodes), k_trace_gi (GI rays drawn, traced and reduced
+        # in place: closest-hit queries of SURVEY 8(d) all the same, counted in closest_rays) and k_trace_shadow
+        kern = "gi" if dominant not in ("closest", "gi", "shadow") else dominant
+        gi_rays = int(work.gi_rays)
+        k_rays = {"closest": work.closest_rays - gi_rays, "gi": gi_rays, "shadow": work.shadow_rays}[kern]
+        k_bytes = bytes_s if kern == "shadow" else bytes_c           # SURVEY 8(d) incl. the geometry term
+        k_stream = 136.0 if kern == "shadow" else 224.0              # SURVEY 8(d) wavefront records only
         k_ms = ms[kern]
         n_launch = max(1.0, launches[kern])
         gbs = lambda nbytes, msec: nbytes / (msec * 1e-3) / 1e9 if msec > 0 else 0.0
@@ -242,7 +245,7 @@ def main():
         # whole frame: HBM bytes of every kernel of one step (PMC, replayed) against the step's wall time
         frame_bytes = None
         if pmc_t:
-            per_step = {"k_trace_closest": launches["closest"], "k_trace_shadow": launches["shadow"]}
+            per_step = {"k_trace_closest": launches["closest"], "k_trace_gi": launches["gi"], "k_trace_shadow": launches["shadow"]}
             tot = 0.0
             for k, rec in pmc_t.items():
                 if not isinstance(rec, dict) or "hbm_bytes_per_launch" not in rec:
@@ -263,8 +266,9 @@ def main():
             "algorithmic_incl_cache_gbs": round(incl_cache_gbs, 2),
             "launches_per_step": launches[kern], "avg_launch_ms": round(k_ms / n_launch, 4),
             "stream_bytes_per_ray": k_stream, "algorithmic_bytes_per_ray_incl_cache": round(k_bytes, 1), "rays_per_step": int(k_rays),
-            "nodes_per_ray": round(nodes_c if kern == "closest" else nodes_s, 2),
-            "prims_per_ray": round(prims_c if kern == "closest" else prims_s, 2),
+            "nodes_per_ray": round(nodes_s if kern == "shadow" else nodes_c, 2),   # closest + gi rays together
+            "prims_per_ray": round(prims_s if kern == "shadow" else prims_c, 2),
+            "gi_query_form": "two-phase" if timed_stats and timed_stats[-1].gi_two_phase else "closest-hit",
             "kernel_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
             "dominant_class": dominant,
             "valu": valu,  # co-limit: VALU issue occupancy / lane use / FP64 rate of the same kernel

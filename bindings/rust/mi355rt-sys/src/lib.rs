@@ -155,6 +155,10 @@ pub struct rt_render_stats {
     pub ms_resolve: f32,
     pub ms_accum: f32,
     pub retries: u32,
+    pub launches_gi: u32,
+    pub ms_gi: f32,
+    pub gi_two_phase: u32,
+    pub gi_rays: u64,
 }
 
 /// Opaque handle owned by the library; one host thread at a time.

@@ -185,6 +185,12 @@ typedef struct rt_render_stats {
     float ms_resolve; /* bottom-up shading resolve                   */
     float ms_accum;   /* per-pixel accumulate                        */
     uint32_t retries; /* batches re-run smaller after a pool overflow */
+    /* global-illumination rays traced in place (k_trace_gi: drawn, traced and reduced per parent hit, no stored ray);
+     * they are part of closest_rays, their kernel time and launches are NOT part of ms_closest / launches_closest */
+    uint32_t launches_gi;
+    float ms_gi;
+    uint32_t gi_two_phase; /* the form of GI query this call used (0: one closest-hit query, 1: two-phase) */
+    uint64_t gi_rays;
 } rt_render_stats;
 
 typedef struct rt_scene rt_scene; /* opaque */

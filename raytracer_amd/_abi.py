@@ -141,6 +141,10 @@ class RenderStats(C.Structure):
         ("ms_resolve", C.c_float),
         ("ms_accum", C.c_float),
         ("retries", C.c_uint32),
+        ("launches_gi", C.c_uint32),
+        ("ms_gi", C.c_float),
+        ("gi_two_phase", C.c_uint32),
+        ("gi_rays", C.c_uint64),
     ]
 
     def as_dict(self):

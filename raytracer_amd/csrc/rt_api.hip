@@ -237,7 +237,7 @@ struct EventTimer {
     }
 };
 
-enum { CLS_RAYGEN = 0, CLS_CLOSEST, CLS_SHADOW, CLS_EXPAND, CLS_RESOLVE, CLS_ACCUM, CLS_MISC, CLS_COUNT };
+enum { CLS_RAYGEN = 0, CLS_CLOSEST, CLS_SHADOW, CLS_EXPAND, CLS_RESOLVE, CLS_ACCUM, CLS_MISC, CLS_GI, CLS_COUNT };
 
 }  // namespace
 
@@ -278,6 +278,20 @@ struct rt_scene {
     uint64_t n_nodes = 0, n_leaves = 0, bvh_depth = 0;
     int n_cus = 256;
     bool bvh_on_device = false;  // the tree was built by rt_bvh_device.hip.h
+    // k_trace_gi answers its rays with one closest-hit query or with two-phase queries (rt_kernels.hip.h); the frames
+    // are the same bit for bit, which of the two is faster depends on the scene (how far max_occlusion_distance
+    // reaches, how much of it the special primitives fill).  When the scene allows two phases and nothing forces the
+    // choice, the first two render calls of at least a million GI rays try one each (k_trace_gi timed with HIP
+    // events) and later calls use the faster.
+    struct GiTune {
+        bool allowed = false;  // special primitives are few enough for the two-phase form to be considered
+        int forced = -1;       // MI355RT_GI_TWO_PHASE=0|1
+        int decided = -1;
+        bool have[2] = {false, false};
+        double ms_per_mray[2] = {0.0, 0.0};
+        int mode() const { return forced >= 0 ? forced : !allowed ? 0 : decided >= 0 ? decided : have[1] ? 0 : 1; }
+        bool exploring() const { return forced < 0 && allowed && decided < 0; }
+    } gi_tune;
 
     uint64_t pool_bytes = 24ull << 30;  // one batch for 800x800x4spp scene.json (108 M nodes); 8 % of the 288 GB
     void *pool_mem = nullptr;
@@ -939,9 +953,9 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     // host in the main tree's quantisation frame, so one CullRay serves both.  MI355RT_GI_TWO_PHASE=0|1 forces the choice.
     BvhBuildResult bvh_s;
     std::vector<LeafPrim> leaf_s;
-    bool two_phase = static_cast<uint64_t>(n_special) * 8u <= d->n_prims;
-    if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) two_phase = std::strcmp(want, "0") != 0;
-    if (two_phase && n_special > 0) {
+    sc->gi_tune.allowed = static_cast<uint64_t>(n_special) * 8u <= d->n_prims;
+    if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) sc->gi_tune.forced = std::strcmp(want, "0") != 0 ? 1 : 0;
+    if ((sc->gi_tune.allowed || sc->gi_tune.forced == 1) && n_special > 0) {
         std::vector<uint32_t> sub;  // indices into bounded_ids
         for (size_t b = 0; b < n_bounded; ++b) {
             const uint32_t f = prim_flags[bounded_ids[b]];
@@ -980,7 +994,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     }
     dev.root_ref_s = bvh_s.root_ref;
     dev.n_special = n_special;
-    dev.gi_two_phase = two_phase ? 1u : 0u;
+    dev.gi_two_phase = static_cast<uint32_t>(sc->gi_tune.mode());
     dev.n_planes = static_cast<uint32_t>(planes.size());
     dev.n_bounded = static_cast<uint32_t>(bounded_ids.size());
     dev.n_prims = d->n_prims;
@@ -1124,6 +1138,16 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     EventTimer timer;
     timer.enabled = stats != nullptr;
     timer.stream = stream;
+    // which form of GI query this call uses; while that is still being tried out, k_trace_gi is timed (the scene's own
+    // context only: the no-allocation path creates no events and takes the choice as it stands)
+    const int gi_mode = s->gi_tune.mode();
+    s->dev.gi_two_phase = static_cast<uint32_t>(gi_mode);
+    EventTimer gi_timer;
+    gi_timer.enabled = s->gi_tune.exploring() && &ctx == &s->ctx && !stats;  // with stats the main timer has the figure
+    gi_timer.stream = stream;
+    const bool gi_tuning = s->gi_tune.exploring() && &ctx == &s->ctx;
+    double gi_ms = 0.0;
+    uint64_t gi_rays_call = 0;
     EventPair call_ev;
     if (stats) {
         HIP_TRY(hipEventCreate(&call_ev.a));
@@ -1168,10 +1192,12 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
                 else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, gp, d_ctr, sh, level);
                 timer.end();
                 if (level + 1 < max_depth && gi_rays_host(s->dev.opts, level) <= GI_MAX_INPLACE) {  // the GI rays of this level's hits, in place
-                    timer.begin(CLS_CLOSEST);
+                    timer.begin(CLS_GI);
+                    gi_timer.begin(CLS_GI);
                     if (count_work) hipLaunchKernelGGL(k_trace_gi<true>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, wl, np, gp, d_ctr, sh, level + 1, stack_entries(s));
                     else hipLaunchKernelGGL(k_trace_gi<false>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, wl, np, gp, d_ctr, sh, level + 1, stack_entries(s));
                     timer.end();
+                    gi_timer.end();
                 }
                 timer.begin(CLS_EXPAND);
                 hipLaunchKernelGGL(k_advance_level, dim3(1), dim3(64), 0, stream, d_ctr, sh, level);
@@ -1237,6 +1263,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         float cls_ms[CLS_COUNT] = {0};
         uint32_t cls_n[CLS_COUNT] = {0};
         timer.collect(cls_ms, cls_n, CLS_COUNT);
+        gi_timer.collect(cls_ms, cls_n, CLS_COUNT);  // only one of the two timers runs
         if (c.overflow) {
             if (n <= wl.ns) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's ray tree");
             batch = std::max<uint64_t>(wl.ns, (n / 2) - (n / 2) % wl.ns);
@@ -1259,6 +1286,11 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         st.batches += 1;
         st.ms_raygen += cls_ms[CLS_RAYGEN];
         st.ms_closest += cls_ms[CLS_CLOSEST];
+        st.ms_gi += cls_ms[CLS_GI];
+        st.launches_gi += cls_n[CLS_GI];
+        st.gi_rays += c.gi_rays;
+        gi_ms += cls_ms[CLS_GI];
+        gi_rays_call += c.gi_rays;
         st.ms_shadow += cls_ms[CLS_SHADOW];
         st.ms_expand += cls_ms[CLS_EXPAND];
         st.ms_resolve += cls_ms[CLS_RESOLVE];
@@ -1288,7 +1320,16 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         ctx.est_jobs_per_item = call_max[2];
         ctx.est_specials_per_item = call_max[3];
     }
+    if (gi_tuning && !count_work && gi_rays_call >= 1000000u && gi_ms > 0.0) {
+        rt_scene::GiTune &t = s->gi_tune;
+        t.have[gi_mode] = true;
+        t.ms_per_mray[gi_mode] = gi_ms / (1e-6 * static_cast<double>(gi_rays_call));
+        if (t.have[0] && t.have[1]) t.decided = t.ms_per_mray[1] <= t.ms_per_mray[0] ? 1 : 0;
+        if (t.decided >= 0 && std::getenv("MI355RT_TIMING"))
+            std::fprintf(stderr, "[mi355rt] GI queries: %.4f ms/Mray in one phase, %.4f in two -> %s\n", t.ms_per_mray[0], t.ms_per_mray[1], t.decided ? "two" : "one");
+    }
     st.ray_count = st.closest_rays + st.shadow_rays;
+    st.gi_two_phase = static_cast<uint32_t>(gi_mode);
     if (stats) {
         HIP_TRY(hipEventRecord(call_ev.b, stream));
         HIP_TRY(hipEventSynchronize(call_ev.b));
