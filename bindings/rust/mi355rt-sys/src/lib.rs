@@ -158,6 +158,8 @@ pub struct rt_render_stats {
     pub launches_gi: u32,
     pub ms_gi: f32,
     pub gi_two_phase: u32,
+    pub gi_waves: u32,
+    pub _pad_gi: u32,
     pub gi_rays: u64,
 }
 

@@ -190,6 +190,8 @@ typedef struct rt_render_stats {
     uint32_t launches_gi;
     float ms_gi;
     uint32_t gi_two_phase; /* the form of GI query this call used (0: one closest-hit query, 1: two-phase) */
+    uint32_t gi_waves;     /* and the k_trace_gi build: register budget for 3 or 4 waves per SIMD */
+    uint32_t _pad_gi;
     uint64_t gi_rays;
 } rt_render_stats;
 

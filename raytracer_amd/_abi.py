@@ -144,6 +144,8 @@ class RenderStats(C.Structure):
         ("launches_gi", C.c_uint32),
         ("ms_gi", C.c_float),
         ("gi_two_phase", C.c_uint32),
+        ("gi_waves", C.c_uint32),
+        ("_pad_gi", C.c_uint32),
         ("gi_rays", C.c_uint64),
     ]
 

@@ -278,19 +278,28 @@ struct rt_scene {
     uint64_t n_nodes = 0, n_leaves = 0, bvh_depth = 0;
     int n_cus = 256;
     bool bvh_on_device = false;  // the tree was built by rt_bvh_device.hip.h
-    // k_trace_gi answers its rays with one closest-hit query or with two-phase queries (rt_kernels.hip.h); the frames
-    // are the same bit for bit, which of the two is faster depends on the scene (how far max_occlusion_distance
-    // reaches, how much of it the special primitives fill).  When the scene allows two phases and nothing forces the
-    // choice, the first two render calls of at least a million GI rays try one each (k_trace_gi timed with HIP
-    // events) and later calls use the faster.
+    // k_trace_gi comes in variants that give the same frames bit for bit: its rays answered by one closest-hit query or
+    // by two-phase queries (rt_kernels.hip.h), its register budget cut for three or for four waves per SIMD.  Which is
+    // fastest depends on the scene (how far max_occlusion_distance reaches, how much of it the special primitives
+    // fill, whether the tree fits the caches).  The variants the scene allows are tried one per render call of at
+    // least a million GI rays (k_trace_gi timed with HIP events); later calls use the fastest.
+    // MI355RT_GI_TWO_PHASE=0|1 and MI355RT_GI_WAVES=3|4 pin a choice.
     struct GiTune {
-        bool allowed = false;  // special primitives are few enough for the two-phase form to be considered
-        int forced = -1;       // MI355RT_GI_TWO_PHASE=0|1
+        struct Variant {
+            uint8_t two_phase, waves;
+        };
+        Variant v[4] = {{0, 4}, {0, 4}, {0, 4}, {0, 4}};
+        int n = 1;
         int decided = -1;
-        bool have[2] = {false, false};
-        double ms_per_mray[2] = {0.0, 0.0};
-        int mode() const { return forced >= 0 ? forced : !allowed ? 0 : decided >= 0 ? decided : have[1] ? 0 : 1; }
-        bool exploring() const { return forced < 0 && allowed && decided < 0; }
+        bool have[4] = {false, false, false, false};
+        double ms_per_mray[4] = {0.0, 0.0, 0.0, 0.0};
+        int pick() const {
+            if (decided >= 0) return decided;
+            for (int i = 0; i < n; ++i)
+                if (!have[i]) return i;
+            return 0;
+        }
+        bool exploring() const { return decided < 0 && n > 1; }
     } gi_tune;
 
     uint64_t pool_bytes = 24ull << 30;  // one batch for 800x800x4spp scene.json (108 M nodes); 8 % of the 288 GB
@@ -953,9 +962,20 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     // host in the main tree's quantisation frame, so one CullRay serves both.  MI355RT_GI_TWO_PHASE=0|1 forces the choice.
     BvhBuildResult bvh_s;
     std::vector<LeafPrim> leaf_s;
-    sc->gi_tune.allowed = static_cast<uint64_t>(n_special) * 8u <= d->n_prims;
-    if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) sc->gi_tune.forced = std::strcmp(want, "0") != 0 ? 1 : 0;
-    if ((sc->gi_tune.allowed || sc->gi_tune.forced == 1) && n_special > 0) {
+    bool build_special_tree = false;
+    {   // the variants of k_trace_gi this scene may use, the likeliest first (small renders never get past it)
+        int tp_lo = 0, tp_hi = static_cast<uint64_t>(n_special) * 8u <= d->n_prims ? 1 : 0;  // two phases: only if the special primitives are few
+        if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) tp_lo = tp_hi = std::strcmp(want, "0") != 0 ? 1 : 0;
+        int w_lo = 3, w_hi = 4;
+        if (const char *want = std::getenv("MI355RT_GI_WAVES")) w_lo = w_hi = std::strcmp(want, "3") == 0 ? 3 : 4;
+        rt_scene::GiTune &t = sc->gi_tune;
+        t.n = 0;
+        for (int tp = tp_hi; tp >= tp_lo; --tp)
+            for (int w = n_bounded >= 32768 ? w_hi : w_lo; w >= w_lo && w <= w_hi; w += n_bounded >= 32768 ? -1 : 1)
+                t.v[t.n++] = rt_scene::GiTune::Variant{static_cast<uint8_t>(tp), static_cast<uint8_t>(w)};
+        build_special_tree = tp_hi == 1;
+    }
+    if (build_special_tree && n_special > 0) {
         std::vector<uint32_t> sub;  // indices into bounded_ids
         for (size_t b = 0; b < n_bounded; ++b) {
             const uint32_t f = prim_flags[bounded_ids[b]];
@@ -994,7 +1014,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     }
     dev.root_ref_s = bvh_s.root_ref;
     dev.n_special = n_special;
-    dev.gi_two_phase = static_cast<uint32_t>(sc->gi_tune.mode());
+    dev.gi_two_phase = sc->gi_tune.v[sc->gi_tune.pick()].two_phase;
     dev.n_planes = static_cast<uint32_t>(planes.size());
     dev.n_bounded = static_cast<uint32_t>(bounded_ids.size());
     dev.n_prims = d->n_prims;
@@ -1140,8 +1160,9 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     timer.stream = stream;
     // which form of GI query this call uses; while that is still being tried out, k_trace_gi is timed (the scene's own
     // context only: the no-allocation path creates no events and takes the choice as it stands)
-    const int gi_mode = s->gi_tune.mode();
-    s->dev.gi_two_phase = static_cast<uint32_t>(gi_mode);
+    const int gi_variant = s->gi_tune.pick();
+    const bool gi_waves3 = s->gi_tune.v[gi_variant].waves == 3;
+    s->dev.gi_two_phase = s->gi_tune.v[gi_variant].two_phase;
     EventTimer gi_timer;
     gi_timer.enabled = s->gi_tune.exploring() && &ctx == &s->ctx && !stats;  // with stats the main timer has the figure
     gi_timer.stream = stream;
@@ -1194,8 +1215,8 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
                 if (level + 1 < max_depth && gi_rays_host(s->dev.opts, level) <= GI_MAX_INPLACE) {  // the GI rays of this level's hits, in place
                     timer.begin(CLS_GI);
                     gi_timer.begin(CLS_GI);
-                    if (count_work) hipLaunchKernelGGL(k_trace_gi<true>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, wl, np, gp, d_ctr, sh, level + 1, stack_entries(s));
-                    else hipLaunchKernelGGL(k_trace_gi<false>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, wl, np, gp, d_ctr, sh, level + 1, stack_entries(s));
+                    auto *kern = count_work ? (gi_waves3 ? k_trace_gi<true, 3> : k_trace_gi<true, 4>) : (gi_waves3 ? k_trace_gi<false, 3> : k_trace_gi<false, 4>);
+                    hipLaunchKernelGGL(kern, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, wl, np, gp, d_ctr, sh, level + 1, stack_entries(s));
                     timer.end();
                     gi_timer.end();
                 }
@@ -1320,16 +1341,26 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         ctx.est_jobs_per_item = call_max[2];
         ctx.est_specials_per_item = call_max[3];
     }
-    if (gi_tuning && !count_work && gi_rays_call >= 1000000u && gi_ms > 0.0) {
+    if (gi_tuning && !count_work && st.retries == 0 && gi_rays_call >= 1000000u && gi_ms > 0.0) {
         rt_scene::GiTune &t = s->gi_tune;
-        t.have[gi_mode] = true;
-        t.ms_per_mray[gi_mode] = gi_ms / (1e-6 * static_cast<double>(gi_rays_call));
-        if (t.have[0] && t.have[1]) t.decided = t.ms_per_mray[1] <= t.ms_per_mray[0] ? 1 : 0;
-        if (t.decided >= 0 && std::getenv("MI355RT_TIMING"))
-            std::fprintf(stderr, "[mi355rt] GI queries: %.4f ms/Mray in one phase, %.4f in two -> %s\n", t.ms_per_mray[0], t.ms_per_mray[1], t.decided ? "two" : "one");
+        t.have[gi_variant] = true;
+        t.ms_per_mray[gi_variant] = gi_ms / (1e-6 * static_cast<double>(gi_rays_call));
+        bool all = true;
+        for (int i = 0; i < t.n; ++i) all = all && t.have[i];
+        if (all) {
+            t.decided = 0;
+            for (int i = 1; i < t.n; ++i)
+                if (t.ms_per_mray[i] < t.ms_per_mray[t.decided]) t.decided = i;
+            if (std::getenv("MI355RT_TIMING")) {
+                std::fprintf(stderr, "[mi355rt] GI queries, ms per million rays:");
+                for (int i = 0; i < t.n; ++i) std::fprintf(stderr, " %s/%u waves %.4f%s", t.v[i].two_phase ? "two-phase" : "closest-hit", t.v[i].waves, t.ms_per_mray[i], i == t.decided ? " <-" : "");
+                std::fprintf(stderr, "\n");
+            }
+        }
     }
     st.ray_count = st.closest_rays + st.shadow_rays;
-    st.gi_two_phase = static_cast<uint32_t>(gi_mode);
+    st.gi_two_phase = s->gi_tune.v[gi_variant].two_phase;
+    st.gi_waves = s->gi_tune.v[gi_variant].waves;
     if (stats) {
         HIP_TRY(hipEventRecord(call_ev.b, stream));
         HIP_TRY(hipEventSynchronize(call_ev.b));

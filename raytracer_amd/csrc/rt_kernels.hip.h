@@ -824,8 +824,12 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
 //   specials       in slot order, the rays whose emissive contribution may be non-zero: a terminal hit on an emissive
 //                  surface (its colour is the material's), or a hit that needs get_emissive_* children (:135-167,
 //                  :263-337) -- only that ray gets a node (ray, path, hit; META_TRACED) and joins the level's nodes.
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_gi(SceneDev sc, WorkList wl, NodePool np, GiPool gp, Counters *ctrs, Shards shards, uint32_t level,
+// WAVES: resident waves per SIMD the register budget is cut for -- 4 (128 VGPRs, some 45 of them spilled: the
+// compiler keeps the sampling routine's f64 constants in registers across the traversal) or 3 (168 VGPRs, 5 spilled).
+// Three are faster where the tree sits in LDS / L2 (scene.json -6 %, cornell_box -12 %), four where its misses need
+// hiding (the 1M-triangle scene +8 % with three); rt_api.hip times both on the scene's first frames.
+template <bool COUNT, int WAVES>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList wl, NodePool np, GiPool gp, Counters *ctrs, Shards shards, uint32_t level,
                                                    uint32_t stack_entries) {
     extern __shared__ __align__(16) uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;

@@ -14,16 +14,21 @@ from conftest import load_scene
 pytestmark = pytest.mark.gpu
 
 
-def _scene(desc, mode, device):
-    old = os.environ.get("MI355RT_GI_TWO_PHASE")
-    os.environ["MI355RT_GI_TWO_PHASE"] = mode
+def _scene(desc, mode, device, waves=None):
+    """A scene pinned to one form of GI query (and one k_trace_gi build): the library reads the pins at rt_scene_create."""
+    pins = {"MI355RT_GI_TWO_PHASE": mode, "MI355RT_GI_WAVES": waves}
+    old = {k: os.environ.get(k) for k in pins}
+    for k, v in pins.items():
+        if v is not None:
+            os.environ[k] = v
     try:
         return device.DeviceScene(desc, pool_bytes=2 << 30)
     finally:
-        if old is None:
-            del os.environ["MI355RT_GI_TWO_PHASE"]
-        else:
-            os.environ["MI355RT_GI_TWO_PHASE"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 # physical / refraction: every primitive is special (the default there is one phase); scene / cornell_box / mesh: a few are
@@ -50,3 +55,31 @@ def test_two_phase_over_occlusion_distances(occlusion):
     acc1, _, n1, _ = one.render(want_rgba=False)
     acc2, _, n2, _ = two.render(want_rgba=False)
     assert n1 == n2 and np.array_equal(acc1, acc2)
+
+
+def test_every_variant_the_library_may_pick_gives_the_same_frame():
+    """rt_api.hip GiTune tries (query form) x (k_trace_gi built for 3 or 4 waves per SIMD) on a scene's first frames and
+    keeps the fastest: whatever it picks, the frame is the same."""
+    from raytracer_amd import device
+
+    s = load_scene("cornell_box", size=160, spp=4)
+    frames, seen = [], set()
+    for mode in ("0", "1"):
+        for waves in ("3", "4"):
+            g = _scene(s.desc, mode, device, waves)
+            acc, _, n, st = g.render(want_rgba=False, want_stats=True)
+            assert (st.gi_two_phase, st.gi_waves) == (int(mode), int(waves))
+            seen.add((st.gi_two_phase, st.gi_waves))
+            frames.append((acc, n))
+    assert len(seen) == 4
+    for acc, n in frames[1:]:
+        assert n == frames[0][1] and np.array_equal(acc, frames[0][0])
+    # unpinned: the first calls walk through the variants (each call of >= 1M GI rays settles one), then one stays
+    g = device.DeviceScene(s.desc, pool_bytes=2 << 30)
+    picks = []
+    for _ in range(7):
+        acc, _, n, st = g.render(want_rgba=False, want_stats=True)
+        assert n == frames[0][1] and np.array_equal(acc, frames[0][0])
+        picks.append((st.gi_two_phase, st.gi_waves))
+    assert st.gi_rays >= 1000000, "the frame is too small to settle a variant"
+    assert len(set(picks[:4])) == 4 and len(set(picks[4:])) == 1, picks

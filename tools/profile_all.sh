@@ -7,6 +7,9 @@ out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o $tag -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_line.json 2> $out/bench.err
+# the PMC passes render two frames: pin the form of GI query the bench settles on for scene.json (closest-hit queries, k_trace_gi built for three waves per SIMD), or the
+# first frames would be its trials of the other variants
+export MI355RT_GI_TWO_PHASE=0 MI355RT_GI_WAVES=3
 pass() { name=$1; shift; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o p -- python3 tools/profile_frame.py scene 2 24 > $out/$name.log 2>&1; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
