@@ -750,8 +750,9 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
     uint32_t *stack = stack_lds + threadIdx.x;
     __shared__ LevelMap map;
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
-    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
+    if (blockIdx.x * (BLOCK / 64) >= n_groups) return;  // no group for this block: leave before staging the tree (the small launches of the deep levels)
+    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     unsigned long long n_nodes = 0, n_prims = 0;
     for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
         uint32_t n_valid;
@@ -836,7 +837,6 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
     __shared__ LevelMap map;
     const ShardCtx c = shard_ctx(ctrs, shards);  // the shard this block ALLOCATES nodes and specials from
     Counters *ctr = c.ctr;
-    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const uint32_t G = gi_rays(sc, level - 1u);                 // rays per job (uniform over the level)
     const uint32_t per_round = 64u / G, used = per_round * G;  // whole jobs per wave round (G <= 64)
     // work map over the jobs of level - 1: "entries" are jobs, a group = per_round jobs
@@ -862,6 +862,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
     }
     __syncthreads();
     const uint32_t n_groups = map.dead ? 0u : map.prefix[shards.count];
+    if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
+    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const uint32_t lane = threadIdx.x & 63u;
     const bool next_real = level + 1u < sc.opts.max_depth;  // children of this level's hits are traced (else they return zero, :495-497)
     unsigned long long n_nodes = 0, n_prims = 0;
@@ -965,8 +967,9 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
     uint32_t *stack = stack_lds + threadIdx.x;
     __shared__ LevelMap map;
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
-    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const uint32_t n_groups = PROBE ? (probe_count + 63u) / 64u : level_map_build(map, ctrs, shards, 0u, true);
+    if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
+    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     unsigned long long n_nodes = 0, n_prims = 0;
     for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
         uint32_t n_valid, i;
