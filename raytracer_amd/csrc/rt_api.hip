@@ -1190,7 +1190,10 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         const Shards sh = plan_shards(ctx, n, wl.ns);
         // traversal: 48 blocks per CU, four resident -- the hardware deals out the rest as blocks finish, which evens out
         // rays of very different cost (4 persistent blocks per CU: scene.json +7 %, the 1M-triangle scene +37 %)
-        const uint32_t g_level = shard_grid(s, sh, static_cast<uint64_t>(s->n_cus) * 48u * BLOCK, 48);
+        // (a small batch -- a 1/8 shard of a frame -- gets fewer blocks, down to 12 per CU: a block's start-up, 16 KB of
+        // tree into LDS, is then shared by as many rays as in a full frame; k_trace_gi of a scene.json shard 1.53 -> 1.37 ms)
+        const uint32_t trace_bpc = static_cast<uint32_t>(std::min<uint64_t>(48, std::max<uint64_t>(12, n * 48 / 2560000)));
+        const uint32_t g_level = shard_grid(s, sh, static_cast<uint64_t>(s->n_cus) * trace_bpc * BLOCK, trace_bpc);
         const uint32_t g_wide = shard_grid(s, sh, static_cast<uint64_t>(gmax) * BLOCK, 8);
 
         timer.begin(CLS_MISC);
