@@ -202,38 +202,48 @@ uint32_t morton2(uint32_t x, uint32_t y) {
 }
 
 struct EventTimer {
-    // accumulates elapsed ms per kernel class from (start, stop) event pairs
+    // accumulates elapsed ms per kernel class from (start, stop) events.  Consecutive spans share an event -- the stop of
+    // one is the start of the next: every hipEventRecord between two kernels costs ~5 us of idle queue (two of them, as
+    // before, 10 us: 0.3 ms of a scene.json frame's 29 class changes)
     struct Span {
-        hipEvent_t a, b;
-        int cls;
+        int a, b, cls;
     };
+    std::vector<hipEvent_t> evs;
     std::vector<Span> spans;
     bool enabled = false;
+    bool chaining = true;  // every launch of the stream lies inside a span (else spans are not adjacent: no sharing)
+    bool chain = false;    // the last recorded event is the stop of the previous span
     hipStream_t stream = nullptr;
+    int mark() {
+        hipEvent_t e = nullptr;
+        hipEventCreate(&e);
+        hipEventRecord(e, stream);
+        evs.push_back(e);
+        return static_cast<int>(evs.size()) - 1;
+    }
     void begin(int cls) {
         if (!enabled) return;
-        Span s{};
-        s.cls = cls;
-        hipEventCreate(&s.a);
-        hipEventCreate(&s.b);
-        hipEventRecord(s.a, stream);
-        spans.push_back(s);
+        const int a = chain && chaining ? static_cast<int>(evs.size()) - 1 : mark();
+        spans.push_back(Span{a, -1, cls});
+        chain = false;
     }
     void end() {
         if (!enabled) return;
-        hipEventRecord(spans.back().b, stream);
+        spans.back().b = mark();
+        chain = true;
     }
     void collect(float *per_class, uint32_t *launches, int n_classes) {
-        for (Span &s : spans) {
+        for (const Span &s : spans) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess && s.cls < n_classes) {
+            if (s.b >= 0 && hipEventElapsedTime(&ms, evs[s.a], evs[s.b]) == hipSuccess && s.cls < n_classes) {
                 per_class[s.cls] += ms;
                 launches[s.cls] += 1;
             }
-            hipEventDestroy(s.a);
-            hipEventDestroy(s.b);
         }
+        for (hipEvent_t e : evs) hipEventDestroy(e);
+        evs.clear();
         spans.clear();
+        chain = false;
     }
 };
 
@@ -1166,6 +1176,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     EventTimer gi_timer;
     gi_timer.enabled = s->gi_tune.exploring() && &ctx == &s->ctx && !stats;  // with stats the main timer has the figure
     gi_timer.stream = stream;
+    gi_timer.chaining = false;
     const bool gi_tuning = s->gi_tune.exploring() && &ctx == &s->ctx;
     double gi_ms = 0.0;
     uint64_t gi_rays_call = 0;
