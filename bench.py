@@ -159,8 +159,8 @@ def main():
         torch.cuda.synchronize()
 
     # scene set-up, not a step: the library settles which variant of k_trace_gi is fastest on this scene during a scene's
-    # first render calls, one variant per call, four at most (rt_api.hip GiTune; the frames are the same bit for bit)
-    for _ in range(4):
+    # first render calls, one variant per call after an untimed first, six at most (rt_api.hip GiTune; the frames are the same bit for bit)
+    for _ in range(7):
         step()
     for _ in range(args.warmup):
         step()
@@ -272,7 +272,7 @@ def main():
             "stream_bytes_per_ray": k_stream, "algorithmic_bytes_per_ray_incl_cache": round(k_bytes, 1), "rays_per_step": int(k_rays),
             "nodes_per_ray": round(nodes_s if kern == "shadow" else nodes_c, 2),   # closest + gi rays together
             "prims_per_ray": round(prims_s if kern == "shadow" else prims_c, 2),
-            "gi_query_form": ("two-phase" if timed_stats and timed_stats[-1].gi_two_phase else "closest-hit") + (f", {timed_stats[-1].gi_waves} waves/SIMD" if timed_stats else ""),
+            "gi_query_form": (("closest-hit", "two-phase (inner levels)", "two-phase (last level)", "two-phase")[timed_stats[-1].gi_two_phase & 3] if timed_stats else "") + (f", {timed_stats[-1].gi_waves} waves/SIMD" if timed_stats else ""),
             "kernel_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
             "dominant_class": dominant,
             "valu": valu,  # co-limit: VALU issue occupancy / lane use / FP64 rate of the same kernel

@@ -189,7 +189,7 @@ typedef struct rt_render_stats {
      * they are part of closest_rays, their kernel time and launches are NOT part of ms_closest / launches_closest */
     uint32_t launches_gi;
     float ms_gi;
-    uint32_t gi_two_phase; /* the form of GI query this call used (0: one closest-hit query, 1: two-phase) */
+    uint32_t gi_two_phase; /* the form of GI query this call used: 0 = one closest-hit query; two-phase on the inner levels (bit 0) / on the last traced level (bit 1) */
     uint32_t gi_waves;     /* and the k_trace_gi build: register budget for 3 or 4 waves per SIMD */
     uint32_t _pad_gi;
     uint64_t gi_rays;

@@ -298,11 +298,12 @@ struct rt_scene {
         struct Variant {
             uint8_t two_phase, waves;
         };
-        Variant v[4] = {{0, 4}, {0, 4}, {0, 4}, {0, 4}};
+        Variant v[6] = {{0, 4}, {0, 4}, {0, 4}, {0, 4}, {0, 4}, {0, 4}};  // two_phase: bit 0 = on the inner levels, bit 1 = on the last traced level
         int n = 1;
         int decided = -1;
-        bool have[4] = {false, false, false, false};
-        double ms_per_mray[4] = {0.0, 0.0, 0.0, 0.0};
+        bool warm = false;  // the scene's first sizeable call is not timed (cold caches and clocks, pool sizing)
+        bool have[6] = {false, false, false, false, false, false};
+        double ms_per_mray[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int pick() const {
             if (decided >= 0) return decided;
             for (int i = 0; i < n; ++i)
@@ -624,7 +625,7 @@ Shards plan_shards(const RenderCtx &c, uint64_t n, uint32_t ns) {
 uint32_t stack_entries(const rt_scene *s) { return static_cast<uint32_t>(s->bvh_depth + 2); }
 uint32_t stack_lds_bytes(const rt_scene *s) {
     static const uint32_t extra = std::getenv("MI355RT_EXTRA_LDS") ? std::atoi(std::getenv("MI355RT_EXTRA_LDS")) : 0;  // occupancy experiments
-    return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + (s->dev.n_top_nodes + s->dev.n_top_s) * static_cast<uint32_t>(sizeof(BvhNode)) + extra;
+    return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + (s->dev.n_top_nodes + s->dev.special[0].n_top + s->dev.special[1].n_top) * static_cast<uint32_t>(sizeof(BvhNode)) + extra;
 }
 
 Shards single_shard(const RenderCtx &c) {
@@ -960,36 +961,47 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     // get_emissive_phong (:135-167) adds a child only if reflectivity > 0; get_emissive_physical (:263-337)
     // only if max_reflected_rays > 0 or opacity < 1: otherwise an illumination ray's result is the emissive colour
     std::vector<uint32_t> prim_flags(d->n_prims);
-    uint32_t n_special = 0;
+    uint32_t n_special[2] = {0, 0};  // [0] emissive or casting child rays, [1] emissive (what is special on the last traced level)
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const rt_material &m = d->materials[shade[i].material];
         const bool terminal = m.kind == RT_MAT_PHONG ? !(m.reflectivity > 0.0) : (o.max_reflected_rays == 0 && !(m.opacity < 1.0));
         const bool emissive = m.emissive[0] != 0.0 || m.emissive[1] != 0.0 || m.emissive[2] != 0.0;
         prim_flags[i] = (terminal ? PRIM_ILLUM_TERMINAL : 0u) | (emissive ? PRIM_EMISSIVE : 0u);
-        if (!terminal || emissive) n_special++;
+        if (!terminal || emissive) n_special[0]++;
+        if (emissive) n_special[1]++;
     }
-    // ---- two-phase GI queries (k_trace_gi): worth it when the special primitives are few.  Their tree is built on the
-    // host in the main tree's quantisation frame, so one CullRay serves both.  MI355RT_GI_TWO_PHASE=0|1 forces the choice.
-    BvhBuildResult bvh_s;
-    std::vector<LeafPrim> leaf_s;
-    bool build_special_tree = false;
-    {   // the variants of k_trace_gi this scene may use, the likeliest first (small renders never get past it)
-        int tp_lo = 0, tp_hi = static_cast<uint64_t>(n_special) * 8u <= d->n_prims ? 1 : 0;  // two phases: only if the special primitives are few
-        if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) tp_lo = tp_hi = std::strcmp(want, "0") != 0 ? 1 : 0;
+    // ---- two-phase GI queries (k_trace_gi): worth considering on the levels whose special primitives are few.  Their
+    // trees are built on the host in the main tree's quantisation frame, so one CullRay serves all.
+    // MI355RT_GI_TWO_PHASE=0|1 forces the choice (1: on every level, whatever the sets' sizes).
+    BvhBuildResult bvh_s[2];
+    std::vector<LeafPrim> leaf_s[2];
+    bool set_ok[2] = {static_cast<uint64_t>(n_special[0]) * 8u <= d->n_prims, static_cast<uint64_t>(n_special[1]) * 8u <= d->n_prims};
+    {   // the variants of k_trace_gi this scene may use, the likeliest first (small renders never get past it): two-phase
+        // queries on every level whose set is small, on the last level only, on none
+        int masks[3], n_masks = 0;
+        if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) {
+            masks[n_masks++] = std::strcmp(want, "0") != 0 ? 3 : 0;
+            set_ok[0] = set_ok[1] = masks[0] != 0;
+        } else {
+            const int all = (set_ok[0] ? 1 : 0) | (set_ok[1] ? 2 : 0);
+            if (all) masks[n_masks++] = all;
+            if (all == 3) masks[n_masks++] = 2;
+            masks[n_masks++] = 0;
+        }
         int w_lo = 3, w_hi = 4;
         if (const char *want = std::getenv("MI355RT_GI_WAVES")) w_lo = w_hi = std::strcmp(want, "3") == 0 ? 3 : 4;
         rt_scene::GiTune &t = sc->gi_tune;
         t.n = 0;
-        for (int tp = tp_hi; tp >= tp_lo; --tp)
+        for (int i = 0; i < n_masks; ++i)
             for (int w = n_bounded >= 32768 ? w_hi : w_lo; w >= w_lo && w <= w_hi; w += n_bounded >= 32768 ? -1 : 1)
-                t.v[t.n++] = rt_scene::GiTune::Variant{static_cast<uint8_t>(tp), static_cast<uint8_t>(w)};
-        build_special_tree = tp_hi == 1;
+                t.v[t.n++] = rt_scene::GiTune::Variant{static_cast<uint8_t>(masks[i]), static_cast<uint8_t>(w)};
     }
-    if (build_special_tree && n_special > 0) {
+    for (int q = 0; q < 2; ++q) {
+        if (!set_ok[q] || n_special[q] == 0) continue;
         std::vector<uint32_t> sub;  // indices into bounded_ids
         for (size_t b = 0; b < n_bounded; ++b) {
             const uint32_t f = prim_flags[bounded_ids[b]];
-            if (!(f & PRIM_ILLUM_TERMINAL) || (f & PRIM_EMISSIVE)) sub.push_back(static_cast<uint32_t>(b));
+            if ((f & PRIM_EMISSIVE) || (q == 0 && !(f & PRIM_ILLUM_TERMINAL))) sub.push_back(static_cast<uint32_t>(b));
         }
         std::vector<Aabb> sub_boxes(sub.size());
         std::vector<uint32_t> sub_group(sub.size());
@@ -997,14 +1009,14 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
             sub_boxes[j] = cull_boxes[sub[j]];
             sub_group[j] = leaf_group[sub[j]];
         }
-        bvh_s = build_bvh(sub_boxes, &sub_group, 0, bvh.q_origin, bvh.q_scale);
-        leaf_s.resize(bvh_s.order.size());
-        for (size_t j = 0; j < leaf_s.size(); ++j) leaf_s[j] = leaf_record(sub[bvh_s.order[j]]);
+        bvh_s[q] = build_bvh(sub_boxes, &sub_group, 0, bvh.q_origin, bvh.q_scale);
+        leaf_s[q].resize(bvh_s[q].order.size());
+        for (size_t j = 0; j < leaf_s[q].size(); ++j) leaf_s[q][j] = leaf_record(sub[bvh_s[q].order[j]]);
     }
     lap("special primitives");
     sc->n_nodes = n_built_nodes;
     sc->n_leaves = bvh.n_leaves;
-    sc->bvh_depth = std::max(bvh.max_depth, bvh_s.max_depth);
+    sc->bvh_depth = std::max(bvh.max_depth, std::max(bvh_s[0].max_depth, bvh_s[1].max_depth));
     lap("leaf records");
 
     // ---- upload
@@ -1020,10 +1032,17 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         const uint32_t budget = 40u * 1024u - 2048u;  // per block; 2 KB for the kernels' static LDS (work map, live-list masks)
         const uint32_t fit = stack_bytes < budget ? (budget - stack_bytes) / static_cast<uint32_t>(sizeof(BvhNode)) : 0u;
         dev.n_top_nodes = static_cast<uint32_t>(std::min<size_t>(n_built_nodes, std::min(fit, 512u)));
-        dev.n_top_s = static_cast<uint32_t>(std::min<size_t>(bvh_s.nodes.size(), std::min(fit - dev.n_top_nodes, 64u)));
+        uint32_t left = fit - dev.n_top_nodes;
+        for (int q = 0; q < 2; ++q) {
+            dev.special[q].n_top = static_cast<uint32_t>(std::min<size_t>(bvh_s[q].nodes.size(), std::min(left, 64u)));
+            left -= dev.special[q].n_top;
+        }
     }
-    dev.root_ref_s = bvh_s.root_ref;
-    dev.n_special = n_special;
+    for (int q = 0; q < 2; ++q) {
+        dev.special[q].root_ref = bvh_s[q].root_ref;
+        dev.special[q].count = n_special[q];
+        dev.special[q].ok = set_ok[q] ? 1u : 0u;
+    }
     dev.gi_two_phase = sc->gi_tune.v[sc->gi_tune.pick()].two_phase;
     dev.n_planes = static_cast<uint32_t>(planes.size());
     dev.n_bounded = static_cast<uint32_t>(bounded_ids.size());
@@ -1066,8 +1085,10 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     else if ((rc = upload(st, bvh.nodes, &dev.nodes, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, leaf, &dev.leaf_prims, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, planes, &dev.planes, sc->allocs, bytes))) return rc;
-    if ((rc = upload(st, bvh_s.nodes, &dev.nodes_s, sc->allocs, bytes))) return rc;
-    if ((rc = upload(st, leaf_s, &dev.leaf_prims_s, sc->allocs, bytes))) return rc;
+    for (int q = 0; q < 2; ++q) {
+        if ((rc = upload(st, bvh_s[q].nodes, &dev.special[q].nodes, sc->allocs, bytes))) return rc;
+        if ((rc = upload(st, leaf_s[q], &dev.special[q].leaf_prims, sc->allocs, bytes))) return rc;
+    }
     if ((rc = upload(st, shade, &dev.shade_prims, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, prim_flags, &dev.prim_flags, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, d->inv_world, 12ull * d->n_transforms, &dev.inv_world, sc->allocs, bytes))) return rc;
@@ -1357,8 +1378,12 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     }
     if (gi_tuning && !count_work && st.retries == 0 && gi_rays_call >= 1000000u && gi_ms > 0.0) {
         rt_scene::GiTune &t = s->gi_tune;
-        t.have[gi_variant] = true;
-        t.ms_per_mray[gi_variant] = gi_ms / (1e-6 * static_cast<double>(gi_rays_call));
+        if (!t.warm) {
+            t.warm = true;
+        } else {
+            t.have[gi_variant] = true;
+            t.ms_per_mray[gi_variant] = gi_ms / (1e-6 * static_cast<double>(gi_rays_call));
+        }
         bool all = true;
         for (int i = 0; i < t.n; ++i) all = all && t.have[i];
         if (all) {
@@ -1367,7 +1392,9 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
                 if (t.ms_per_mray[i] < t.ms_per_mray[t.decided]) t.decided = i;
             if (std::getenv("MI355RT_TIMING")) {
                 std::fprintf(stderr, "[mi355rt] GI queries, ms per million rays:");
-                for (int i = 0; i < t.n; ++i) std::fprintf(stderr, " %s/%u waves %.4f%s", t.v[i].two_phase ? "two-phase" : "closest-hit", t.v[i].waves, t.ms_per_mray[i], i == t.decided ? " <-" : "");
+                for (int i = 0; i < t.n; ++i)
+                    std::fprintf(stderr, " %s/%uw %.4f%s", t.v[i].two_phase == 3 ? "two-phase" : t.v[i].two_phase == 2 ? "two-phase(last level)" : t.v[i].two_phase ? "two-phase(inner levels)" : "closest-hit",
+                                 t.v[i].waves, t.ms_per_mray[i], i == t.decided ? " <-" : "");
                 std::fprintf(stderr, "\n");
             }
         }

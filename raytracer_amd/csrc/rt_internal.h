@@ -110,14 +110,19 @@ struct SceneDev {
     double scene_scale;   // max |coordinate| of the root box
     float q_origin[3];    // node boxes: coordinate = q_origin + q * q_scale (q = 0..65535)
     float q_scale[3];
-    // two-phase GI queries (k_trace_gi): the special primitives -- emissive, or an illumination hit needs child rays
-    // (PRIM_* flags) -- have a tree of their own, in the frame of the main one; used when they are few
-    const BvhNode *nodes_s;
-    const LeafPrim *leaf_prims_s;
-    uint32_t root_ref_s;    // 0xFFFFFFFF: no bounded special primitive
-    uint32_t n_top_s;       // nodes of that tree kept in LDS behind the main tree's
-    uint32_t n_special;     // special primitives, planes included
-    uint32_t gi_two_phase;  // k_trace_gi: closest special hit + any-hit instead of one closest-hit query
+    // two-phase GI queries (k_trace_gi): the special primitives have a tree of their own, in the frame of the main one.
+    // Which primitives are special depends on the level: where the hit's own children would still be traced, the
+    // emissive ones and those that cast child rays (PRIM_* flags); on the last traced level -- children return zero,
+    // :495-497 -- the emissive ones only.  A set is usable when it is small (`ok`).
+    struct SpecialSet {
+        const BvhNode *nodes;
+        const LeafPrim *leaf_prims;
+        uint32_t root_ref;  // 0xFFFFFFFF: no bounded primitive in the set
+        uint32_t n_top;     // nodes of the tree kept in LDS behind the main tree's (set 0, then set 1)
+        uint32_t count;     // primitives in the set, planes included
+        uint32_t ok;        // the set is small enough for two-phase queries to be considered
+    } special[2];           // [0] inner levels, [1] the last traced level
+    uint32_t gi_two_phase;  // k_trace_gi: closest special hit + any-hit instead of one closest-hit query; bit 0 inner levels, bit 1 last level (where the set is ok)
     // shading
     const ShadePrim *shade_prims;
     const uint32_t *prim_flags;  // primitive-ID order, PRIM_* bits

@@ -541,13 +541,17 @@ __device__ __forceinline__ const uint4 *stage_top_nodes(const SceneDev &sc, uint
     uint4 *top = reinterpret_cast<uint4 *>(stack_lds + stack_entries * BLOCK);
     const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes);
     for (uint32_t i = threadIdx.x; i < sc.n_top_nodes * 2u; i += BLOCK) top[i] = src[i];
-    const uint4 *src_s = reinterpret_cast<const uint4 *>(sc.nodes_s);  // the tree of the special primitives, behind it
-    for (uint32_t i = threadIdx.x; i < sc.n_top_s * 2u; i += BLOCK) top[sc.n_top_nodes * 2u + i] = src_s[i];
+    uint32_t at = sc.n_top_nodes * 2u;  // the trees of the special primitives behind it
+    for (uint32_t q = 0; q < 2; ++q) {
+        const uint4 *src_s = reinterpret_cast<const uint4 *>(sc.special[q].nodes);
+        for (uint32_t i = threadIdx.x; i < sc.special[q].n_top * 2u; i += BLOCK) top[at + i] = src_s[i];
+        at += sc.special[q].n_top * 2u;
+    }
     __syncthreads();
     return top;
 }
 
-// One of the scene's two trees: all bounded primitives, or the special ones only (SceneDev::nodes_s).
+// One of the scene's trees: all bounded primitives, or one of the two sets of special ones (SceneDev::special).
 struct TreeView {
     const BvhNode *nodes;
     const LeafPrim *leaf_prims;
@@ -558,8 +562,9 @@ struct TreeView {
 __device__ __forceinline__ TreeView main_tree(const SceneDev &sc, const uint4 *top_nodes) {
     return TreeView{sc.nodes, sc.leaf_prims, top_nodes, sc.n_top_nodes, sc.root_ref};
 }
-__device__ __forceinline__ TreeView special_tree(const SceneDev &sc, const uint4 *top_nodes) {
-    return TreeView{sc.nodes_s, sc.leaf_prims_s, top_nodes + 2u * sc.n_top_nodes, sc.n_top_s, sc.root_ref_s};
+__device__ __forceinline__ TreeView special_tree(const SceneDev &sc, const uint4 *top_nodes, uint32_t set) {
+    const SceneDev::SpecialSet &sp = sc.special[set];
+    return TreeView{sp.nodes, sp.leaf_prims, top_nodes + 2u * (sc.n_top_nodes + (set ? sc.special[0].n_top : 0u)), sp.n_top, sp.root_ref};
 }
 
 // Descend from `cur` through interior nodes until a leaf ref or the sentinel.
@@ -606,7 +611,8 @@ __device__ __forceinline__ uint32_t descend(const TreeView &tv, const CullRay &c
 template <bool COUNT, bool SPECIAL>
 __device__ __forceinline__ void closest_hit(const SceneDev &sc, const TreeView &tv, uint32_t *stack, const RayD &ray, Counters *ctr,
                                             unsigned long long &n_nodes, unsigned long long &n_prims, uint32_t *id_out, double *t_out,
-                                            double *bu_out, double *bv_out, const CullRay *shared_cr = nullptr, uint32_t *key_out = nullptr) {
+                                            double *bu_out, double *bv_out, const CullRay *shared_cr = nullptr, uint32_t *key_out = nullptr,
+                                            bool emissive_only = false) {
     double best_t = __builtin_inf();
     uint32_t best_id = RT_NO_HIT;
     double best_bu = 0.0, best_bv = 0.0;
@@ -615,7 +621,7 @@ __device__ __forceinline__ void closest_hit(const SceneDev &sc, const TreeView &
 
     for (uint32_t p = 0; p < sc.n_planes; ++p) {  // unbounded objects first (bounds.rs:303-305)
         const PlanePrim pl = sc.planes[p];
-        if (SPECIAL && !is_special(sc.prim_flags[pl.prim_id])) continue;
+        if (SPECIAL && !(emissive_only ? (sc.prim_flags[pl.prim_id] & PRIM_EMISSIVE) != 0 : is_special(sc.prim_flags[pl.prim_id]))) continue;
         const double *inv = sc.inv_world + 12ull * (pl.meta >> 4);
         RayD orr;
         orr.o = xf_point(inv, ray.o);
@@ -866,6 +872,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
     const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const uint32_t lane = threadIdx.x & 63u;
     const bool next_real = level + 1u < sc.opts.max_depth;  // children of this level's hits are traced (else they return zero, :495-497)
+    const uint32_t set = next_real ? 0u : 1u;                // which primitives are special on this level
+    const bool two_phase = ((sc.gi_two_phase >> set) & 1u) && sc.special[set].ok;
     unsigned long long n_nodes = 0, n_prims = 0;
     uint32_t wave_rays = 0, wave_nodes = 0;  // wave-uniform
     for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
@@ -887,10 +895,11 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
             rng_pair(wl.seed, job.pixel, job.sample, path_child(job.path, SLOT_GI + slot), &u1, &u2);
             ray.d = sample_direction(SAMPLE_HEMISPHERE, n, 0.0, u1, u2);
             ray.o = P + ray.d * BIAS;  // :115
-            if (sc.gi_two_phase) {  // closest special hit, then: does anything precede it / lie within the occlusion distance?
+            if (two_phase) {  // closest special hit, then: does anything precede it / lie within the occlusion distance?
                 const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
                 uint32_t s_key = 0;
-                if (sc.n_special) closest_hit<COUNT, true>(sc, special_tree(sc, top_nodes), stack, ray, ctr, n_nodes, n_prims, &hit_id, &hit_t, &hit_bu, &hit_bv, &cr, &s_key);
+                if (sc.special[set].count)
+                    closest_hit<COUNT, true>(sc, special_tree(sc, top_nodes, set), stack, ray, ctr, n_nodes, n_prims, &hit_id, &hit_t, &hit_bu, &hit_bv, &cr, &s_key, set == 1u);
                 plain = any_hit_before<COUNT>(sc, main_tree(sc, top_nodes), stack, ray, cr, n_nodes, n_prims, hit_id != RT_NO_HIT, hit_t, s_key,
                                               sc.opts.max_occlusion_distance);
             } else {

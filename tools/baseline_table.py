@@ -21,7 +21,7 @@ def bytes_per_ray(kind, nodes, prims, tri_share):
 
 def row(label, scene, cpu_rows):
     g = device.DeviceScene(scene.desc)
-    for _ in range(5):  # first frames: pool sizing, and the library tries its k_trace_gi variants (at most four)
+    for _ in range(8):  # first frames: pool sizing, and the library tries its k_trace_gi variants (at most six)
         g.render(want_rgba=False)
     best = None
     for _ in range(3):
@@ -44,7 +44,7 @@ def row(label, scene, cpu_rows):
     r = {"config": label, "camera_rays": wd * h * int(scene.opts.samples_per_pixel), "primitives": int(scene.n_prims), "rays": int(n),
          "gpu_ms": round(best.ms_total, 2), "gpu_mrays": round(n / best.ms_total / 1e3, 1),
          "ms": {k: round(getattr(best, "ms_" + k), 2) for k in ("closest", "gi", "shadow", "expand", "resolve")}, "batches": int(best.batches),
-         "gi_variant": ("two-phase" if best.gi_two_phase else "closest-hit") + f"/{best.gi_waves}w",
+         "gi_variant": ("closest-hit", "two-phase(inner)", "two-phase(last)", "two-phase")[best.gi_two_phase & 3] + f"/{best.gi_waves}w",
          "nodes_per_ray": round(nc, 2), "prims_per_ray": round(pc, 2),
          "frac_hbm_stream_closest": round(gbs(w.closest_rays * 224.0, ms_hit) / HBM, 3),
          "frac_hbm_stream_frame": round(gbs(w.closest_rays * 224.0 + w.shadow_rays * 136.0, best.ms_total) / HBM, 3),
