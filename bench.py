@@ -33,6 +33,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PUBLISHED = {}         # BASELINE.json "published": {} -> vs_baseline is null
 
 
+def _gi_form(bits):
+    """rt_render_stats.gi_two_phase -> words (rt_api.hip GiTune)."""
+    on = [w for i, w in enumerate(("GI rays of inner levels", "GI rays of the last level", "illumination nodes of the last level")) if bits >> i & 1]
+    return "two-phase queries for " + " + ".join(on) if on else "closest-hit queries"
+
+
 def algorithmic_bytes(kind, nodes_per_ray, tri_per_ray, analytic_per_ray):
     """closest-hit ray 224 B, shadow ray 136 B of wavefront
     records + 64 B per BVH2 node visited + 72 B per triangle / 104 B per
@@ -159,8 +165,8 @@ def main():
         torch.cuda.synchronize()
 
     # scene set-up, not a step: the library settles which variant of k_trace_gi is fastest on this scene during a scene's
-    # first render calls, one variant per call after an untimed first, six at most (rt_api.hip GiTune; the frames are the same bit for bit)
-    for _ in range(7):
+    # first render calls (an untimed one, one with its starting configuration, one per switch: six at most) (rt_api.hip GiTune; the frames are the same bit for bit)
+    for _ in range(6):
         step()
     for _ in range(args.warmup):
         step()
@@ -206,8 +212,8 @@ def main():
         prim_types = scene.prim_types()
         tri_share = float((prim_types == _abi.RT_PRIM_TRIANGLE).mean()) if len(prim_types) else 0.0
         n_steps = max(1, len(timed_stats))
-        ms = {k: sum(getattr(s, "ms_" + k) for s in timed_stats) / n_steps for k in ("raygen", "closest", "gi", "shadow", "expand", "resolve", "accum")}
-        launches = {k: sum(getattr(s, "launches_" + k) for s in timed_stats) / n_steps for k in ("closest", "gi", "shadow")}
+        ms = {k: sum(getattr(s, "ms_" + k) for s in timed_stats) / n_steps for k in ("raygen", "closest", "gi", "illum", "shadow", "expand", "resolve", "accum")}
+        launches = {k: sum(getattr(s, "launches_" + k) for s in timed_stats) / n_steps for k in ("closest", "gi", "illum", "shadow")}
         nodes_c = work.nodes_visited_closest / max(1, work.closest_rays)
         prims_c = work.prims_tested_closest / max(1, work.closest_rays)
         nodes_s = work.nodes_visited_shadow / max(1, work.shadow_rays)
@@ -217,9 +223,9 @@ def main():
         dominant = max(ms, key=ms.get)
         # the three traversal kernels: k_trace_closest (rays stored as nodes), k_trace_gi (GI rays drawn, traced and reduced
         # in place: closest-hit queries of SURVEY 8(d) all the same, counted in closest_rays) and k_trace_shadow
-        kern = "gi" if dominant not in ("closest", "gi", "shadow") else dominant
-        gi_rays = int(work.gi_rays)
-        k_rays = {"closest": work.closest_rays - gi_rays, "gi": gi_rays, "shadow": work.shadow_rays}[kern]
+        kern = "gi" if dominant not in ("closest", "gi", "illum", "shadow") else dominant
+        gi_rays, illum_rays = int(work.gi_rays), int(work.illum_rays)  # k_trace_illum_last: the last level's illumination nodes (two-phase queries)
+        k_rays = {"closest": work.closest_rays - gi_rays - illum_rays, "gi": gi_rays, "illum": illum_rays, "shadow": work.shadow_rays}[kern]
         k_bytes = bytes_s if kern == "shadow" else bytes_c           # SURVEY 8(d) incl. the geometry term
         k_stream = 136.0 if kern == "shadow" else 224.0              # SURVEY 8(d) wavefront records only
         k_ms = ms[kern]
@@ -239,17 +245,18 @@ def main():
                 pmc_t, pmc_v = {}, {}
         src_t = f"profiles/pmc_traffic.json ({pmc_t.get('_tree', 'r01g')}), replayed" if pmc_t else None
         src_v = f"profiles/pmc_valu.json ({pmc_v.get('_tree', 'r01g')}), replayed" if pmc_v else None
-        traffic = pmc_t.get("k_trace_" + kern, {}).get("hbm_bytes_per_launch")
+        KERNEL_OF = {"closest": "k_trace_closest", "gi": "k_trace_gi", "illum": "k_trace_illum_last", "shadow": "k_trace_shadow"}
+        traffic = pmc_t.get(KERNEL_OF[kern], {}).get("hbm_bytes_per_launch")
         measured_gbs = gbs(traffic * n_launch, k_ms) if traffic else None
         valu = None
-        if pmc_v.get("k_trace_" + kern):
-            v = pmc_v["k_trace_" + kern]
+        if pmc_v.get(KERNEL_OF[kern]):
+            v = pmc_v[KERNEL_OF[kern]]
             valu = {k: v[k] for k in ("valu_busy", "lane_use", "fp64_tflops", "fp64_frac_of_peak", "wait_share") if k in v}
             valu["source"] = src_v
         # whole frame: HBM bytes of every kernel of one step (PMC, replayed) against the step's wall time
         frame_bytes = None
         if pmc_t:
-            per_step = {"k_trace_closest": launches["closest"], "k_trace_gi": launches["gi"], "k_trace_shadow": launches["shadow"]}
+            per_step = {KERNEL_OF[k]: launches[k] for k in KERNEL_OF}
             tot = 0.0
             for k, rec in pmc_t.items():
                 if not isinstance(rec, dict) or "hbm_bytes_per_launch" not in rec:
@@ -263,7 +270,7 @@ def main():
             # ray (136 B per shadow ray), which every design must move once -- over its HIP-event time.  The geometry term of
             # 8(d) (64 B per node visit, 72 / 104 B per primitive test) is cache traffic for scenes that fit L2 / LDS and is
             # reported apart (`algorithmic_incl_cache_gbs`: not a bound, it exceeds the HBM peak on L2-resident scenes).
-            "bound": bound, "kernel": "k_trace_" + kern, "achieved": round(stream_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": bound, "kernel": KERNEL_OF[kern], "achieved": round(stream_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(stream_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src_t,
             "frac_hbm_stream": round(stream_gbs / HBM_PEAK_GBS, 4),
             "frac_hbm_measured": round(measured_gbs / HBM_PEAK_GBS, 4) if measured_gbs else None,
@@ -272,7 +279,7 @@ def main():
             "stream_bytes_per_ray": k_stream, "algorithmic_bytes_per_ray_incl_cache": round(k_bytes, 1), "rays_per_step": int(k_rays),
             "nodes_per_ray": round(nodes_s if kern == "shadow" else nodes_c, 2),   # closest + gi rays together
             "prims_per_ray": round(prims_s if kern == "shadow" else prims_c, 2),
-            "gi_query_form": (("closest-hit", "two-phase (inner levels)", "two-phase (last level)", "two-phase")[timed_stats[-1].gi_two_phase & 3] if timed_stats else "") + (f", {timed_stats[-1].gi_waves} waves/SIMD" if timed_stats else ""),
+            "gi_query_form": (_gi_form(timed_stats[-1].gi_two_phase) if timed_stats else "") + (f", {timed_stats[-1].gi_waves} waves/SIMD" if timed_stats else ""),
             "kernel_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
             "dominant_class": dominant,
             "valu": valu,  # co-limit: VALU issue occupancy / lane use / FP64 rate of the same kernel

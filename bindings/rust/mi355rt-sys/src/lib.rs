@@ -161,6 +161,9 @@ pub struct rt_render_stats {
     pub gi_waves: u32,
     pub _pad_gi: u32,
     pub gi_rays: u64,
+    pub illum_rays: u64,
+    pub ms_illum: f32,
+    pub launches_illum: u32,
 }
 
 /// Opaque handle owned by the library; one host thread at a time.

@@ -193,6 +193,11 @@ typedef struct rt_render_stats {
     uint32_t gi_waves;     /* and the k_trace_gi build: register budget for 3 or 4 waves per SIMD */
     uint32_t _pad_gi;
     uint64_t gi_rays;
+    /* illumination rays of the last traced level answered by k_trace_illum_last (two-phase queries; part of closest_rays,
+     * their time and launches are not part of ms_closest / ms_gi) */
+    uint64_t illum_rays;
+    float ms_illum;
+    uint32_t launches_illum;
 } rt_render_stats;
 
 typedef struct rt_scene rt_scene; /* opaque */

@@ -147,6 +147,9 @@ class RenderStats(C.Structure):
         ("gi_waves", C.c_uint32),
         ("_pad_gi", C.c_uint32),
         ("gi_rays", C.c_uint64),
+        ("illum_rays", C.c_uint64),
+        ("ms_illum", C.c_float),
+        ("launches_illum", C.c_uint32),
     ]
 
     def as_dict(self):

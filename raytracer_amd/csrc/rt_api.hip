@@ -247,7 +247,7 @@ struct EventTimer {
     }
 };
 
-enum { CLS_RAYGEN = 0, CLS_CLOSEST, CLS_SHADOW, CLS_EXPAND, CLS_RESOLVE, CLS_ACCUM, CLS_MISC, CLS_GI, CLS_COUNT };
+enum { CLS_RAYGEN = 0, CLS_CLOSEST, CLS_SHADOW, CLS_EXPAND, CLS_RESOLVE, CLS_ACCUM, CLS_MISC, CLS_GI, CLS_ILLUM, CLS_COUNT };
 
 }  // namespace
 
@@ -288,29 +288,41 @@ struct rt_scene {
     uint64_t n_nodes = 0, n_leaves = 0, bvh_depth = 0;
     int n_cus = 256;
     bool bvh_on_device = false;  // the tree was built by rt_bvh_device.hip.h
-    // k_trace_gi comes in variants that give the same frames bit for bit: its rays answered by one closest-hit query or
-    // by two-phase queries (rt_kernels.hip.h), its register budget cut for three or for four waves per SIMD.  Which is
-    // fastest depends on the scene (how far max_occlusion_distance reaches, how much of it the special primitives
-    // fill, whether the tree fits the caches).  The variants the scene allows are tried one per render call of at
-    // least a million GI rays (k_trace_gi timed with HIP events); later calls use the fastest.
-    // MI355RT_GI_TWO_PHASE=0|1 and MI355RT_GI_WAVES=3|4 pin a choice.
+    // The closest-hit work of a frame has switches that leave the frame the same bit for bit and change its speed:
+    //   GI_INNER   k_trace_gi answers the GI rays of the inner levels with two-phase queries (rt_kernels.hip.h)
+    //   GI_LAST    ... and those of the last traced level (there only emissive primitives are special)
+    //   ILLUM_LAST the last level's illumination NODES go to k_trace_illum_last (two-phase) instead of k_trace_closest
+    //   WAVES3     k_trace_gi / k_trace_illum_last built for three waves per SIMD (168 VGPRs, no spills) instead of four
+    // Which setting is fastest depends on the scene (how far max_occlusion_distance reaches, how much of it the
+    // special primitives fill, whether the tree fits the caches).  After an untimed first call the library times the
+    // closest-hit kernels of one render call (of at least a million GI rays) with its starting configuration, then
+    // flips the switches the scene allows one after the other, a call each, keeping a flip that is faster: 1 + (number
+    // of switches) calls, 5 at most.  MI355RT_GI_TWO_PHASE=0|1 and MI355RT_GI_WAVES=3|4 pin switches.
     struct GiTune {
-        struct Variant {
-            uint8_t two_phase, waves;
-        };
-        Variant v[6] = {{0, 4}, {0, 4}, {0, 4}, {0, 4}, {0, 4}, {0, 4}};  // two_phase: bit 0 = on the inner levels, bit 1 = on the last traced level
-        int n = 1;
-        int decided = -1;
-        bool warm = false;  // the scene's first sizeable call is not timed (cold caches and clocks, pool sizing)
-        bool have[6] = {false, false, false, false, false, false};
-        double ms_per_mray[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        int pick() const {
-            if (decided >= 0) return decided;
-            for (int i = 0; i < n; ++i)
-                if (!have[i]) return i;
-            return 0;
+        enum : uint32_t { GI_INNER = 1, GI_LAST = 2, ILLUM_LAST = 4, WAVES3 = 8 };
+        uint32_t cfg = 0;        // best configuration so far
+        double best_ms = 0.0;    // its closest-hit kernels' ms per million closest-hit rays
+        uint32_t dims[4] = {0, 0, 0, 0};  // switches that may be flipped
+        int n_dims = 0;
+        int step = -1;           // -1: warm-up call pending; 0: measuring cfg; i >= 1: trying cfg ^ dims[i - 1]; > n_dims: settled
+        double tried_ms[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // for the MI355RT_TIMING report
+        uint32_t tried_cfg[5] = {0, 0, 0, 0, 0};
+        bool exploring() const { return n_dims > 0 && step <= n_dims; }
+        uint32_t pick() const { return step >= 1 && step <= n_dims ? cfg ^ dims[step - 1] : cfg; }
+        void record(uint32_t ran, double ms) {  // a call with configuration `ran` measured `ms`
+            if (step < 0) {
+                step = 0;  // the scene's first sizeable call is not used (cold caches and clocks, pool sizing)
+                return;
+            }
+            if (step > n_dims) return;
+            tried_cfg[step] = ran;
+            tried_ms[step] = ms;
+            if (step == 0 || ms < best_ms) {
+                cfg = ran;
+                best_ms = ms;
+            }
+            ++step;
         }
-        bool exploring() const { return decided < 0 && n > 1; }
     } gi_tune;
 
     uint64_t pool_bytes = 24ull << 30;  // one batch for 800x800x4spp scene.json (108 M nodes); 8 % of the 288 GB
@@ -976,25 +988,22 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     BvhBuildResult bvh_s[2];
     std::vector<LeafPrim> leaf_s[2];
     bool set_ok[2] = {static_cast<uint64_t>(n_special[0]) * 8u <= d->n_prims, static_cast<uint64_t>(n_special[1]) * 8u <= d->n_prims};
-    {   // the variants of k_trace_gi this scene may use, the likeliest first (small renders never get past it): two-phase
-        // queries on every level whose set is small, on the last level only, on none
-        int masks[3], n_masks = 0;
-        if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) {
-            masks[n_masks++] = std::strcmp(want, "0") != 0 ? 3 : 0;
-            set_ok[0] = set_ok[1] = masks[0] != 0;
-        } else {
-            const int all = (set_ok[0] ? 1 : 0) | (set_ok[1] ? 2 : 0);
-            if (all) masks[n_masks++] = all;
-            if (all == 3) masks[n_masks++] = 2;
-            masks[n_masks++] = 0;
-        }
-        int w_lo = 3, w_hi = 4;
-        if (const char *want = std::getenv("MI355RT_GI_WAVES")) w_lo = w_hi = std::strcmp(want, "3") == 0 ? 3 : 4;
+    {   // the starting configuration (what small renders stay with) and the switches the tuner may flip
         rt_scene::GiTune &t = sc->gi_tune;
-        t.n = 0;
-        for (int i = 0; i < n_masks; ++i)
-            for (int w = n_bounded >= 32768 ? w_hi : w_lo; w >= w_lo && w <= w_hi; w += n_bounded >= 32768 ? -1 : 1)
-                t.v[t.n++] = rt_scene::GiTune::Variant{static_cast<uint8_t>(masks[i]), static_cast<uint8_t>(w)};
+        using T = rt_scene::GiTune;
+        if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) {
+            set_ok[0] = set_ok[1] = std::strcmp(want, "0") != 0;
+            t.cfg = set_ok[0] ? (T::GI_INNER | T::GI_LAST | T::ILLUM_LAST) : 0u;
+        } else {
+            if (set_ok[0]) t.cfg |= T::GI_INNER, t.dims[t.n_dims++] = T::GI_INNER;
+            if (set_ok[1]) t.cfg |= T::GI_LAST | T::ILLUM_LAST, t.dims[t.n_dims++] = T::GI_LAST, t.dims[t.n_dims++] = T::ILLUM_LAST;
+        }
+        if (const char *want = std::getenv("MI355RT_GI_WAVES")) {
+            if (std::strcmp(want, "3") == 0) t.cfg |= T::WAVES3;
+        } else {
+            if (n_bounded < 32768) t.cfg |= T::WAVES3;
+            t.dims[t.n_dims++] = T::WAVES3;
+        }
     }
     for (int q = 0; q < 2; ++q) {
         if (!set_ok[q] || n_special[q] == 0) continue;
@@ -1043,7 +1052,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         dev.special[q].count = n_special[q];
         dev.special[q].ok = set_ok[q] ? 1u : 0u;
     }
-    dev.gi_two_phase = sc->gi_tune.v[sc->gi_tune.pick()].two_phase;
+    dev.gi_two_phase = sc->gi_tune.pick() & 7u;
     dev.n_planes = static_cast<uint32_t>(planes.size());
     dev.n_bounded = static_cast<uint32_t>(bounded_ids.size());
     dev.n_prims = d->n_prims;
@@ -1191,16 +1200,16 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     timer.stream = stream;
     // which form of GI query this call uses; while that is still being tried out, k_trace_gi is timed (the scene's own
     // context only: the no-allocation path creates no events and takes the choice as it stands)
-    const int gi_variant = s->gi_tune.pick();
-    const bool gi_waves3 = s->gi_tune.v[gi_variant].waves == 3;
-    s->dev.gi_two_phase = s->gi_tune.v[gi_variant].two_phase;
+    const uint32_t gi_cfg = s->gi_tune.pick();
+    const bool gi_waves3 = (gi_cfg & rt_scene::GiTune::WAVES3) != 0;
+    s->dev.gi_two_phase = gi_cfg & 7u;
     EventTimer gi_timer;
     gi_timer.enabled = s->gi_tune.exploring() && &ctx == &s->ctx && !stats;  // with stats the main timer has the figure
     gi_timer.stream = stream;
     gi_timer.chaining = false;
     const bool gi_tuning = s->gi_tune.exploring() && &ctx == &s->ctx;
     double gi_ms = 0.0;
-    uint64_t gi_rays_call = 0;
+    uint64_t gi_rays_call = 0, tune_rays_call = 0;
     EventPair call_ev;
     if (stats) {
         HIP_TRY(hipEventCreate(&call_ev.a));
@@ -1237,10 +1246,22 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         if (max_depth > 0) {
             for (uint32_t level = 0; level < max_depth; ++level) {
                 const uint32_t g = level == 0 ? shard_grid(s, sh, n, 48) : g_level;
+                // the last traced level's illumination nodes take two-phase queries over the emissive set, in a kernel of their own
+                const uint32_t illum_apart = level > 0 && level + 1 == max_depth && (s->dev.gi_two_phase & 4u) && s->dev.special[1].ok ? 1u : 0u;
                 timer.begin(CLS_CLOSEST);
-                if (count_work) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s));
-                else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s));
+                gi_timer.begin(CLS_CLOSEST);
+                if (count_work) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s), illum_apart);
+                else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s), illum_apart);
                 timer.end();
+                gi_timer.end();
+                if (illum_apart) {
+                    timer.begin(CLS_ILLUM);
+                    gi_timer.begin(CLS_ILLUM);
+                    auto *kern = count_work ? (gi_waves3 ? k_trace_illum_last<true, 3> : k_trace_illum_last<true, 4>) : (gi_waves3 ? k_trace_illum_last<false, 3> : k_trace_illum_last<false, 4>);
+                    hipLaunchKernelGGL(kern, dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s));
+                    timer.end();
+                    gi_timer.end();
+                }
                 timer.begin(CLS_EXPAND);
                 hipLaunchKernelGGL(k_build_live, dim3(level == 0 ? shard_grid(s, sh, n / 4 + 1, 8) : g_wide), dim3(BLOCK), 0, stream, np, d_ctr, sh, level);
                 const uint32_t ge = level == 0 ? shard_grid(s, sh, n, 8) : g_wide;
@@ -1290,6 +1311,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
             c.special_alloc += ck.special_alloc;
             c.gi_rays += ck.gi_rays;
             c.gi_materialised += ck.gi_materialised;
+            c.illum_last_rays += ck.illum_last_rays;
             c.overflow |= ck.overflow;
             c.active_camera += ck.active_camera;
             c.nodes_visited_closest += ck.nodes_visited_closest;
@@ -1345,8 +1367,12 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         st.ms_gi += cls_ms[CLS_GI];
         st.launches_gi += cls_n[CLS_GI];
         st.gi_rays += c.gi_rays;
-        gi_ms += cls_ms[CLS_GI];
+        st.ms_illum += cls_ms[CLS_ILLUM];
+        st.launches_illum += cls_n[CLS_ILLUM];
+        st.illum_rays += c.illum_last_rays;
+        gi_ms += cls_ms[CLS_GI] + cls_ms[CLS_ILLUM] + cls_ms[CLS_CLOSEST];  // the tuner compares all closest-hit work: variants move rays between the kernels
         gi_rays_call += c.gi_rays;
+        tune_rays_call += closest;
         st.ms_shadow += cls_ms[CLS_SHADOW];
         st.ms_expand += cls_ms[CLS_EXPAND];
         st.ms_resolve += cls_ms[CLS_RESOLVE];
@@ -1378,30 +1404,19 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     }
     if (gi_tuning && !count_work && st.retries == 0 && gi_rays_call >= 1000000u && gi_ms > 0.0) {
         rt_scene::GiTune &t = s->gi_tune;
-        if (!t.warm) {
-            t.warm = true;
-        } else {
-            t.have[gi_variant] = true;
-            t.ms_per_mray[gi_variant] = gi_ms / (1e-6 * static_cast<double>(gi_rays_call));
-        }
-        bool all = true;
-        for (int i = 0; i < t.n; ++i) all = all && t.have[i];
-        if (all) {
-            t.decided = 0;
-            for (int i = 1; i < t.n; ++i)
-                if (t.ms_per_mray[i] < t.ms_per_mray[t.decided]) t.decided = i;
-            if (std::getenv("MI355RT_TIMING")) {
-                std::fprintf(stderr, "[mi355rt] GI queries, ms per million rays:");
-                for (int i = 0; i < t.n; ++i)
-                    std::fprintf(stderr, " %s/%uw %.4f%s", t.v[i].two_phase == 3 ? "two-phase" : t.v[i].two_phase == 2 ? "two-phase(last level)" : t.v[i].two_phase ? "two-phase(inner levels)" : "closest-hit",
-                                 t.v[i].waves, t.ms_per_mray[i], i == t.decided ? " <-" : "");
-                std::fprintf(stderr, "\n");
-            }
+        t.record(gi_cfg, gi_ms / (1e-6 * static_cast<double>(tune_rays_call)));
+        if (!t.exploring() && std::getenv("MI355RT_TIMING")) {
+            std::fprintf(stderr, "[mi355rt] closest-hit kernels, ms per million closest-hit rays:");
+            for (int i = 0; i <= t.n_dims; ++i)
+                std::fprintf(stderr, " [%s%s%s%s]=%.4f", t.tried_cfg[i] & 1u ? "I" : "-", t.tried_cfg[i] & 2u ? "L" : "-", t.tried_cfg[i] & 4u ? "N" : "-", t.tried_cfg[i] & 8u ? "3" : "4",
+                             t.tried_ms[i]);
+            std::fprintf(stderr, " -> [%s%s%s%s]  (I / L: two-phase GI queries on inner / last level, N: last level's illumination nodes apart, 3 / 4: waves per SIMD)\n",
+                         t.cfg & 1u ? "I" : "-", t.cfg & 2u ? "L" : "-", t.cfg & 4u ? "N" : "-", t.cfg & 8u ? "3" : "4");
         }
     }
     st.ray_count = st.closest_rays + st.shadow_rays;
-    st.gi_two_phase = s->gi_tune.v[gi_variant].two_phase;
-    st.gi_waves = s->gi_tune.v[gi_variant].waves;
+    st.gi_two_phase = gi_cfg & 7u;
+    st.gi_waves = gi_waves3 ? 3u : 4u;
     if (stats) {
         HIP_TRY(hipEventRecord(call_ev.b, stream));
         HIP_TRY(hipEventSynchronize(call_ev.b));

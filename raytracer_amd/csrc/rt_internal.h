@@ -229,6 +229,7 @@ struct Counters {
     uint32_t job_level_start[MAX_LEVELS + 1];  // jobs left by k_expand(level): [job_level_start[level], job_alloc) until the level is closed
     unsigned long long gi_rays;          // GI rays traced in place
     unsigned long long gi_materialised;  // of which got a node (also counted in level_count)
+    unsigned long long illum_last_rays;  // illumination nodes of the last traced level answered by k_trace_illum_last
     uint32_t live_colour[MAX_LEVELS + 1], live_illum[MAX_LEVELS + 1];  // entries of NodePool::live per level
     uint32_t overflow;       // a pool ran out: the batch must be re-run smaller
     uint32_t active_camera;  // camera rays inside the window

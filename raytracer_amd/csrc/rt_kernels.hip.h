@@ -329,7 +329,7 @@ __global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
     ctr->job_alloc = 0;
     ctr->special_alloc = 0;
     for (uint32_t i = 0; i <= MAX_LEVELS; ++i) ctr->job_level_start[i] = 0;
-    ctr->gi_rays = ctr->gi_materialised = 0;
+    ctr->gi_rays = ctr->gi_materialised = ctr->illum_last_rays = 0;
     ctr->overflow = local > sh.node_cap ? 1u : 0u;
     ctr->active_camera = 0;
     ctr->nodes_visited_closest = ctr->prims_tested_closest = 0;
@@ -751,7 +751,7 @@ __device__ __forceinline__ uint32_t any_hit_before(const SceneDev &sc, const Tre
 // is 80 % of all nodes.
 template <bool COUNT, bool FINALIZE>
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev sc, NodePool np, Counters *ctrs, Shards shards,
-                                                        uint32_t level, uint32_t stack_entries) {
+                                                        uint32_t level, uint32_t stack_entries, uint32_t skip_illum = 0) {
     extern __shared__ __align__(16) uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;
     __shared__ LevelMap map;
@@ -770,6 +770,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
             continue;
         }
         if (meta & META_TRACED) continue;  // a GI ray k_trace_gi gave a node of its own: hit already stored
+        if (skip_illum && (meta & META_ILLUM)) continue;  // the last level's illumination nodes are k_trace_illum_last's
         RayD ray;
         load_ray(np, idx, &ray.o, &ray.d);
         double best_t, best_bu, best_bv;
@@ -961,6 +962,62 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
         atomicAdd(&ctr->gi_rays, static_cast<unsigned long long>(wave_rays));
         if (wave_nodes) atomicAdd(&ctr->gi_materialised, static_cast<unsigned long long>(wave_nodes));
     }
+    if (COUNT) {
+        atomicAdd(&ctr->nodes_visited_closest, n_nodes & ((1ull << 40) - 1ull));
+        atomicAdd(&ctr->prims_tested_closest, n_prims & ((1ull << 40) - 1ull));
+    }
+}
+
+// The illumination nodes of the LAST traced level (get_illumination, :492-520, whose own children return zero, :495-497):
+// each is finished by its trace -- emissive colour of the hit, occluded or not -- so, as in k_trace_gi, only an
+// emissive primitive needs to be identified; anything else that comes first only has to be known to come first and to
+// lie within max_occlusion_distance or not.  Two-phase queries over the emissive set (SceneDev::special[1]); the
+// colour nodes of the level stay with k_trace_closest (launched with skip_illum).  physical.json: 164 M of these.
+template <bool COUNT, int WAVES>
+__global__ __launch_bounds__(BLOCK, WAVES) void k_trace_illum_last(SceneDev sc, NodePool np, Counters *ctrs, Shards shards, uint32_t level,
+                                                                 uint32_t stack_entries) {
+    extern __shared__ __align__(16) uint32_t stack_lds[];
+    uint32_t *stack = stack_lds + threadIdx.x;
+    __shared__ LevelMap map;
+    Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
+    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
+    if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
+    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
+    unsigned long long n_nodes = 0, n_prims = 0;
+    uint32_t wave_rays = 0;
+    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
+        uint32_t n_valid;
+        const uint32_t idx = level_map_group(map, shards, g, &n_valid) + (threadIdx.x & 63u);
+        bool mine = (threadIdx.x & 63u) < n_valid;
+        uint32_t meta = 0;
+        if (mine) {
+            meta = np.meta[idx];
+            mine = (meta & META_ILLUM) && !(meta & (META_INACTIVE | META_TRACED | META_DONE));
+        }
+        wave_rays += static_cast<uint32_t>(__popcll(__ballot(mine)));
+        if (!mine) continue;
+        RayD ray;
+        load_ray(np, idx, &ray.o, &ray.d);
+        const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
+        uint32_t s_id = RT_NO_HIT, s_key = 0;
+        double s_t = 0.0, s_bu, s_bv;
+        if (sc.special[1].count)
+            closest_hit<COUNT, true>(sc, special_tree(sc, top_nodes, 1u), stack, ray, ctr, n_nodes, n_prims, &s_id, &s_t, &s_bu, &s_bv, &cr, &s_key, true);
+        const uint32_t plain = any_hit_before<COUNT>(sc, main_tree(sc, top_nodes), stack, ray, cr, n_nodes, n_prims, s_id != RT_NO_HIT, s_t, s_key,
+                                                     sc.opts.max_occlusion_distance);
+        const bool emissive_hit = s_id != RT_NO_HIT && !(plain & 1u);
+        uint32_t flag = (plain & 1u) ? ((plain & 2u) ? 1u : 0u) : (emissive_hit && s_t <= sc.opts.max_occlusion_distance ? 1u : 0u);  // :512-516
+        if (emissive_hit) {  // every primitive of the set is emissive
+            const rt_material &m = sc.materials[sc.shade_prims[s_id].material];
+            flag |= 2u;
+            np.t[idx] = m.emissive[0];
+            np.bu[idx] = m.emissive[1];
+            np.bv[idx] = m.emissive[2];
+        }
+        np.meta[idx] = meta | META_DONE;
+        np.prim[idx] = flag;
+    }
+    if ((threadIdx.x & 63u) == 0 && wave_rays) atomicAdd(&ctr->illum_last_rays, static_cast<unsigned long long>(wave_rays));
     if (COUNT) {
         atomicAdd(&ctr->nodes_visited_closest, n_nodes & ((1ull << 40) - 1ull));
         atomicAdd(&ctr->prims_tested_closest, n_prims & ((1ull << 40) - 1ull));

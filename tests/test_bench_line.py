@@ -30,13 +30,13 @@ def test_single_gpu_line():
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_hbm_stream", "frac_hbm_measured", "launches_per_step", "avg_launch_ms",
               "kernel_ms_per_step", "frame", "gi_query_form"):
         assert k in r, k
-    assert r["kernel"] in ("k_trace_closest", "k_trace_gi", "k_trace_shadow") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["kernel"] in ("k_trace_closest", "k_trace_gi", "k_trace_illum_last", "k_trace_shadow") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     fracs = [r["frac"], r["frac_hbm_stream"], r["frame"]["frac_hbm_stream"]] + [x for x in (r["frac_hbm_measured"], r["frame"]["frac_hbm_measured"]) if x is not None]
     assert all(0.0 < f <= 1.0 for f in fracs), fracs
     # the class the line names is the one with the largest time, and its launches and time are those of that class alone
     ms = r["kernel_ms_per_step"]
-    assert set(ms) == {"raygen", "closest", "gi", "shadow", "expand", "resolve", "accum"}
+    assert set(ms) == {"raygen", "closest", "gi", "illum", "shadow", "expand", "resolve", "accum"}
     assert r["dominant_class"] == max(ms, key=ms.get)
     if r["dominant_class"] in ("closest", "gi", "shadow"):
         assert r["kernel"] == "k_trace_" + r["dominant_class"]

@@ -21,7 +21,7 @@ def bytes_per_ray(kind, nodes, prims, tri_share):
 
 def row(label, scene, cpu_rows):
     g = device.DeviceScene(scene.desc)
-    for _ in range(8):  # first frames: pool sizing, and the library tries its k_trace_gi variants (at most six)
+    for _ in range(7):  # first frames: pool sizing, and the library settles its closest-hit switches (six calls at most)
         g.render(want_rgba=False)
     best = None
     for _ in range(3):
@@ -33,7 +33,7 @@ def row(label, scene, cpu_rows):
     tri = float((types == _abi.RT_PRIM_TRIANGLE).mean()) if len(types) else 0.0
     nc, pc = w.nodes_visited_closest / max(1, w.closest_rays), w.prims_tested_closest / max(1, w.closest_rays)
     bc = bytes_per_ray("closest", nc, pc, tri)
-    ms_hit = best.ms_closest + best.ms_gi  # k_trace_closest + k_trace_gi: every closest-hit query of the frame
+    ms_hit = best.ms_closest + best.ms_gi + best.ms_illum  # k_trace_closest + k_trace_gi + k_trace_illum_last: every closest-hit query of the frame
     gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     h, wd = int(scene.opts.height), int(scene.opts.width)
     y0 = (h - cpu_rows) // 2
@@ -43,8 +43,8 @@ def row(label, scene, cpu_rows):
     dt = time.perf_counter() - t0
     r = {"config": label, "camera_rays": wd * h * int(scene.opts.samples_per_pixel), "primitives": int(scene.n_prims), "rays": int(n),
          "gpu_ms": round(best.ms_total, 2), "gpu_mrays": round(n / best.ms_total / 1e3, 1),
-         "ms": {k: round(getattr(best, "ms_" + k), 2) for k in ("closest", "gi", "shadow", "expand", "resolve")}, "batches": int(best.batches),
-         "gi_variant": ("closest-hit", "two-phase(inner)", "two-phase(last)", "two-phase")[best.gi_two_phase & 3] + f"/{best.gi_waves}w",
+         "ms": {k: round(getattr(best, "ms_" + k), 2) for k in ("closest", "gi", "illum", "shadow", "expand", "resolve")}, "batches": int(best.batches),
+         "gi_variant": "".join(c if best.gi_two_phase >> i & 1 else "-" for i, c in enumerate("ILN")) + f"/{best.gi_waves}w",
          "nodes_per_ray": round(nc, 2), "prims_per_ray": round(pc, 2),
          "frac_hbm_stream_closest": round(gbs(w.closest_rays * 224.0, ms_hit) / HBM, 3),
          "frac_hbm_stream_frame": round(gbs(w.closest_rays * 224.0 + w.shadow_rays * 136.0, best.ms_total) / HBM, 3),

@@ -17,7 +17,7 @@ for gib in pools:
         dt = time.perf_counter() - t0
         d = st.as_dict()
         ksum = sum(d[k] for k in d if k.startswith("ms_") and k != "ms_total")
-        print(f"pool {gib:5.2f} GiB it{it}: wall {dt*1e3:7.1f} ms total {d['ms_total']:7.1f} kernels {ksum:6.1f} | closest {d['ms_closest']:6.2f} gi {d['ms_gi']:6.2f} ({('one','inner','last','two')[d['gi_two_phase']]}/{d['gi_waves']}w) shadow {d['ms_shadow']:5.2f} "
+        print(f"pool {gib:5.2f} GiB it{it}: wall {dt*1e3:7.1f} ms total {d['ms_total']:7.1f} kernels {ksum:6.1f} | closest {d['ms_closest']:6.2f} gi {d['ms_gi']:6.2f} ({''.join(c if d['gi_two_phase'] >> i & 1 else '-' for i, c in enumerate('ILN'))}/{d['gi_waves']}w) illum {d['ms_illum']:5.2f} shadow {d['ms_shadow']:5.2f} "
               f"expand {d['ms_expand']:6.2f} resolve {d['ms_resolve']:5.2f} | batches {d['batches']} retries {d['retries']} rays {n} -> {n/d['ms_total']/1e3:7.1f} Mrays/s", flush=True)
     print(g.info())
     g.close()

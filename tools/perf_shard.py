@@ -18,5 +18,5 @@ for stats in (True,):
         cnt, st = g.render_device(acc.data_ptr(), p, stream=stream, want_stats=stats)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) * 1e3
-        k = sum(getattr(st, "ms_" + x) for x in ("raygen", "closest", "gi", "shadow", "expand", "resolve", "accum")) if stats else float("nan")
-        print(f"shards {n} tile {tile} stats {stats} it{it}: wall {dt:6.2f} ms  event total {st.ms_total if stats else float('nan'):6.2f}  kernels {k:6.2f}  rays {cnt}  batches {st.batches if stats else -1} | " + (" ".join(f"{x} {getattr(st, 'ms_' + x):.2f}" for x in ("raygen", "closest", "gi", "shadow", "expand", "resolve", "accum")) if stats else ""), flush=True)
+        k = sum(getattr(st, "ms_" + x) for x in ("raygen", "closest", "gi", "illum", "shadow", "expand", "resolve", "accum")) if stats else float("nan")
+        print(f"shards {n} tile {tile} stats {stats} it{it}: wall {dt:6.2f} ms  event total {st.ms_total if stats else float('nan'):6.2f}  kernels {k:6.2f}  rays {cnt}  batches {st.batches if stats else -1} | " + (" ".join(f"{x} {getattr(st, 'ms_' + x):.2f}" for x in ("raygen", "closest", "gi", "illum", "shadow", "expand", "resolve", "accum")) if stats else ""), flush=True)
