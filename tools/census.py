@@ -1,7 +1,7 @@
 import sys
 sys.path.insert(0, ".")
 from raytracer_amd import _abi, device, host
-s = host.LoadedScene.from_file("scenes/scene.json")
+s = host.LoadedScene.from_file(f"scenes/{sys.argv[1] if len(sys.argv) > 1 else 'scene'}.json")
 g = device.DeviceScene(s.desc)
 for _ in range(5): g.render(want_rgba=False)
 _, _, n, st = g.render(_abi.RenderParams(flags=_abi.RT_FLAG_COUNT_WORK), want_rgba=False, want_stats=True)
