@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rt_bvh.h"
+#include "rt_tune.h"
 #include "rt_bvh_device.hip.h"
 #include "rt_internal.h"
 #include "rt_kernels.hip.h"
@@ -288,42 +289,7 @@ struct rt_scene {
     uint64_t n_nodes = 0, n_leaves = 0, bvh_depth = 0;
     int n_cus = 256;
     bool bvh_on_device = false;  // the tree was built by rt_bvh_device.hip.h
-    // The closest-hit work of a frame has switches that leave the frame the same bit for bit and change its speed:
-    //   GI_INNER   k_trace_gi answers the GI rays of the inner levels with two-phase queries (rt_kernels.hip.h)
-    //   GI_LAST    ... and those of the last traced level (there only emissive primitives are special)
-    //   ILLUM_LAST the last level's illumination NODES go to k_trace_illum_last (two-phase) instead of k_trace_closest
-    //   WAVES3     k_trace_gi / k_trace_illum_last built for three waves per SIMD (168 VGPRs, no spills) instead of four
-    // Which setting is fastest depends on the scene (how far max_occlusion_distance reaches, how much of it the
-    // special primitives fill, whether the tree fits the caches).  After an untimed first call the library times the
-    // closest-hit kernels of one render call (of at least a million GI rays) with its starting configuration, then
-    // flips the switches the scene allows one after the other, a call each, keeping a flip that is faster: 1 + (number
-    // of switches) calls, 5 at most.  MI355RT_GI_TWO_PHASE=0|1 and MI355RT_GI_WAVES=3|4 pin switches.
-    struct GiTune {
-        enum : uint32_t { GI_INNER = 1, GI_LAST = 2, ILLUM_LAST = 4, WAVES3 = 8 };
-        uint32_t cfg = 0;        // best configuration so far
-        double best_ms = 0.0;    // its closest-hit kernels' ms per million closest-hit rays
-        uint32_t dims[4] = {0, 0, 0, 0};  // switches that may be flipped
-        int n_dims = 0;
-        int step = -1;           // -1: warm-up call pending; 0: measuring cfg; i >= 1: trying cfg ^ dims[i - 1]; > n_dims: settled
-        double tried_ms[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // for the MI355RT_TIMING report
-        uint32_t tried_cfg[5] = {0, 0, 0, 0, 0};
-        bool exploring() const { return n_dims > 0 && step <= n_dims; }
-        uint32_t pick() const { return step >= 1 && step <= n_dims ? cfg ^ dims[step - 1] : cfg; }
-        void record(uint32_t ran, double ms) {  // a call with configuration `ran` measured `ms`
-            if (step < 0) {
-                step = 0;  // the scene's first sizeable call is not used (cold caches and clocks, pool sizing)
-                return;
-            }
-            if (step > n_dims) return;
-            tried_cfg[step] = ran;
-            tried_ms[step] = ms;
-            if (step == 0 || ms < best_ms) {
-                cfg = ran;
-                best_ms = ms;
-            }
-            ++step;
-        }
-    } gi_tune;
+    GiTune gi_tune;  // rt_tune.h
 
     uint64_t pool_bytes = 24ull << 30;  // one batch for 800x800x4spp scene.json (108 M nodes); 8 % of the 288 GB
     void *pool_mem = nullptr;
@@ -988,23 +954,8 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     BvhBuildResult bvh_s[2];
     std::vector<LeafPrim> leaf_s[2];
     bool set_ok[2] = {static_cast<uint64_t>(n_special[0]) * 8u <= d->n_prims, static_cast<uint64_t>(n_special[1]) * 8u <= d->n_prims};
-    {   // the starting configuration (what small renders stay with) and the switches the tuner may flip
-        rt_scene::GiTune &t = sc->gi_tune;
-        using T = rt_scene::GiTune;
-        if (const char *want = std::getenv("MI355RT_GI_TWO_PHASE")) {
-            set_ok[0] = set_ok[1] = std::strcmp(want, "0") != 0;
-            t.cfg = set_ok[0] ? (T::GI_INNER | T::GI_LAST | T::ILLUM_LAST) : 0u;
-        } else {
-            if (set_ok[0]) t.cfg |= T::GI_INNER, t.dims[t.n_dims++] = T::GI_INNER;
-            if (set_ok[1]) t.cfg |= T::GI_LAST | T::ILLUM_LAST, t.dims[t.n_dims++] = T::GI_LAST, t.dims[t.n_dims++] = T::ILLUM_LAST;
-        }
-        if (const char *want = std::getenv("MI355RT_GI_WAVES")) {
-            if (std::strcmp(want, "3") == 0) t.cfg |= T::WAVES3;
-        } else {
-            if (n_bounded < 32768) t.cfg |= T::WAVES3;
-            t.dims[t.n_dims++] = T::WAVES3;
-        }
-    }
+    // the starting configuration (what small renders stay with) and the switches the tuner may flip
+    sc->gi_tune.configure(set_ok, n_bounded >= 32768, std::getenv("MI355RT_GI_TWO_PHASE"), std::getenv("MI355RT_GI_WAVES"));
     for (int q = 0; q < 2; ++q) {
         if (!set_ok[q] || n_special[q] == 0) continue;
         std::vector<uint32_t> sub;  // indices into bounded_ids
@@ -1201,7 +1152,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     // which form of GI query this call uses; while that is still being tried out, k_trace_gi is timed (the scene's own
     // context only: the no-allocation path creates no events and takes the choice as it stands)
     const uint32_t gi_cfg = s->gi_tune.pick();
-    const bool gi_waves3 = (gi_cfg & rt_scene::GiTune::WAVES3) != 0;
+    const bool gi_waves3 = (gi_cfg & GiTune::WAVES3) != 0;
     s->dev.gi_two_phase = gi_cfg & 7u;
     EventTimer gi_timer;
     gi_timer.enabled = s->gi_tune.exploring() && &ctx == &s->ctx && !stats;  // with stats the main timer has the figure
@@ -1403,7 +1354,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         ctx.est_specials_per_item = call_max[3];
     }
     if (gi_tuning && !count_work && st.retries == 0 && gi_rays_call >= 1000000u && gi_ms > 0.0) {
-        rt_scene::GiTune &t = s->gi_tune;
+        GiTune &t = s->gi_tune;
         t.record(gi_cfg, gi_ms / (1e-6 * static_cast<double>(tune_rays_call)));
         if (!t.exploring() && std::getenv("MI355RT_TIMING")) {
             std::fprintf(stderr, "[mi355rt] closest-hit kernels, ms per million closest-hit rays:");

@@ -1,6 +1,7 @@
 // CPU harness for tests/test_bvh_build.py: builds the BVH of N pseudo-random boxes with 1 and with 8 workers and
 // checks (a) both trees are byte-identical, (b) every primitive sits in exactly one leaf, (c) every node's
-// (dequantised) child box contains the boxes of all primitives below it, (d) depth fits the traversal stack.
+// (dequantised) child box contains the boxes of all primitives below it, (d) depth fits the traversal stack, (e) the
+// same containment for a tree over a subset built in the full tree's quantisation frame.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,6 +78,43 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < a.nodes.size(); ++i) {
         if (!(a.nodes[i].left & LEAF_FLAG) && a.nodes[i].left <= i) ok = false;
         if (!(a.nodes[i].right & LEAF_FLAG) && a.nodes[i].right <= i) ok = false;
+    }
+    // (e) a tree over a subset of the boxes, quantised in the full tree's frame (the trees of the special primitives,
+    // rt_api.hip: traversed with the main tree's CullRay): its frame is the full tree's, its boxes contain what is below
+    {
+        std::vector<Aabb> sub;
+        for (uint32_t i = 0; i < n; i += 7) sub.push_back(boxes[i]);
+        const BvhBuildResult c = build_bvh(sub, nullptr, 1, a.q_origin, a.q_scale);
+        for (int k = 0; k < 3; ++k)
+            if (c.q_origin[k] != a.q_origin[k] || c.q_scale[k] != a.q_scale[k]) ok = false;
+        std::vector<uint32_t> seen_c(sub.size(), 0);
+        std::function<Aabb(uint32_t)> walk_c = [&](uint32_t ref) -> Aabb {
+            Aabb u{{1e300, 1e300, 1e300}, {-1e300, -1e300, -1e300}};
+            if (ref & LEAF_FLAG) {
+                const uint32_t first = ref & 0x0FFFFFFFu, cnt = ((ref >> 28) & 7u) + 1u;
+                for (uint32_t i = first; i < first + cnt; ++i) {
+                    const uint32_t p = c.order[i];
+                    seen_c[p]++;
+                    for (int k = 0; k < 3; ++k) {
+                        u.mn[k] = std::min(u.mn[k], sub[p].mn[k]);
+                        u.mx[k] = std::max(u.mx[k], sub[p].mx[k]);
+                    }
+                }
+                return u;
+            }
+            const BvhNode &nd = c.nodes[ref];
+            const Aabb l = walk_c(nd.left), r = walk_c(nd.right);
+            for (int k = 0; k < 3; ++k) {
+                if (deq(nd.lmin[k], k) > l.mn[k] || deq(nd.lmax[k], k) < l.mx[k]) ok = false;
+                if (deq(nd.rmin[k], k) > r.mn[k] || deq(nd.rmax[k], k) < r.mx[k]) ok = false;
+                u.mn[k] = std::min(l.mn[k], r.mn[k]);
+                u.mx[k] = std::max(l.mx[k], r.mx[k]);
+            }
+            return u;
+        };
+        if (!sub.empty() && c.root_ref != 0xFFFFFFFFu) walk_c(c.root_ref);
+        for (uint32_t x : seen_c)
+            if (x != 1) ok = false;
     }
     std::printf("%s nodes %zu leaves %u depth %u\n", ok ? "OK" : "FAIL", a.nodes.size(), a.n_leaves, a.max_depth);
     return ok ? 0 : 1;
