@@ -85,3 +85,21 @@ def test_every_variant_the_library_may_pick_gives_the_same_frame():
     assert st.gi_rays >= 1000000, "the frame is too small to settle anything"
     assert picks[0] == picks[1] == (7, 3), picks
     assert len(set(picks[1:6])) == 5 and len(set(picks[6:])) == 1, picks
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_two_phase_on_random_scenes(seed):
+    """Seeded random scenes (tests/random_scenes.py): special PLANES (emissive, mirrors), special and plain primitives
+    overlapping at random, every material kind and side -- forced two-phase queries (both special sets, whatever their
+    size, and k_trace_illum_last) against closest-hit queries, bit for bit."""
+    from raytracer_amd import device, host
+    from conftest import SCENES
+    from random_scenes import random_scene
+
+    s = host.LoadedScene.from_string(random_scene(seed), asset_base=SCENES)
+    one, two = _scene(s.desc, "0", device), _scene(s.desc, "1", device)
+    acc1, _, n1, st1 = one.render(want_rgba=False, want_stats=True)
+    acc2, _, n2, st2 = two.render(want_rgba=False, want_stats=True)
+    assert st2.gi_two_phase == 7 and st1.gi_two_phase == 0
+    assert n1 == n2 and st1.closest_rays == st2.closest_rays and st1.shadow_rays == st2.shadow_rays
+    assert np.array_equal(acc1, acc2)
