@@ -215,6 +215,12 @@ struct EventTimer {
     bool chaining = true;  // every launch of the stream lies inside a span (else spans are not adjacent: no sharing)
     bool chain = false;    // the last recorded event is the stop of the previous span
     hipStream_t stream = nullptr;
+    EventTimer() = default;
+    EventTimer(const EventTimer &) = delete;
+    EventTimer &operator=(const EventTimer &) = delete;
+    ~EventTimer() {  // an early error return leaves events behind
+        for (hipEvent_t e : evs) hipEventDestroy(e);
+    }
     int mark() {
         hipEvent_t e = nullptr;
         hipEventCreate(&e);
