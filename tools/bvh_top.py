@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Development aid: the top three levels of scene.json's BVH as resident on the device (child boxes dequantised, leaf primitive ids)."""
 import sys
 sys.path.insert(0, ".")
 import numpy as np

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Development aid: one RT_FLAG_COUNT_WORK frame of a scene after the tuner has settled (MI355RT_CENSUS=1 prints node kinds per level): census.py [SCENE]"""
 import sys
 sys.path.insert(0, ".")
 from raytracer_amd import _abi, device, host

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Development aid: rt_scene_create on the 1M-triangle synthetic scene, three times (MI355RT_TIMING=1 prints the phases)."""
 import os, sys, tempfile, time
 sys.path.insert(0, ".")
 from raytracer_amd import device, host, synthetic

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Development aid: how a frame's rays split into classes (camera, GI in place, last-level illumination nodes, shadow): ray_classes.py SCENE..."""
 import sys
 sys.path.insert(0, ".")
 from raytracer_amd import device, host
