@@ -303,7 +303,7 @@ int rt_trace_rays(rt_scene *scene, uint32_t n, const double *origin, const doubl
                   const double *tmax, int shadow, uint32_t *prim_id, double *t);
 
 /* BVH facts for reports: node count, leaf count, max depth, bytes resident,
- * bounded / unbounded primitive counts, node / shadow pool capacities. */
+ * bounded / unbounded primitive counts, node / job pool capacities. */
 int rt_scene_info(rt_scene *scene, uint64_t *out8);
 
 /* The acceleration structure as resident on the device, for checks and reports (the counterpart of nothing in the

@@ -263,7 +263,6 @@ enum { CLS_RAYGEN = 0, CLS_CLOSEST, CLS_SHADOW, CLS_EXPAND, CLS_RESOLVE, CLS_ACC
 // static device scratch (one per device, fixed size).
 struct RenderCtx {
     NodePool np{};
-    ShadowPool sp{};
     GiPool gp{};
     Counters *d_ctr = nullptr;
     Counters *h_ctr = nullptr;  // host copy of the counters (pinned for a scene's own context)
@@ -274,17 +273,16 @@ struct RenderCtx {
     rt_render_params plan_key{};
     WorkList plan_wl{};
     bool plan_scattered = false;  // plan_wl is in scattered order (a call of several batches)
-    double est_nodes_per_item = 0.0, est_shadows_per_item = 0.0, est_jobs_per_item = 0.0, est_specials_per_item = 0.0;
+    double est_nodes_per_item = 0.0, est_jobs_per_item = 0.0, est_specials_per_item = 0.0;
     // camera rays one batch can hold, from the largest expansion seen so far (0: nothing seen yet)
     double fit_items() const {
         if (!(est_nodes_per_item > 0.0)) return 0.0;
         double fit = np.capacity / est_nodes_per_item;
-        fit = std::min(fit, sp.capacity / std::max(est_shadows_per_item, 1e-9));
         fit = std::min(fit, gp.job_capacity / std::max(est_jobs_per_item, 1e-9));
         fit = std::min(fit, gp.special_capacity / std::max(est_specials_per_item, 1e-9));
         return fit;
     }
-    void forget_estimates() { est_nodes_per_item = est_shadows_per_item = est_jobs_per_item = est_specials_per_item = 0.0; }
+    void forget_estimates() { est_nodes_per_item = est_jobs_per_item = est_specials_per_item = 0.0; }
 };
 
 struct rt_scene {
@@ -347,19 +345,18 @@ struct rt_scene {
 
 namespace {
 
-// Pool shares.  With the GI rays traced in place a frame's nodes are the camera rays, reflection / refraction children
-// and the 1-in-10 GI rays that go on; shadow rays outnumber them (scene.json: 36 M nodes, 39 M shadow rays, 14 M GI jobs,
-// 7 M specials).  Per node: ray 64 + hit 28 + expansion info 16 + live 4 + job index 4 = 116 bytes; 1.5 shadow rays of 34
-// bytes; half a GI job of 80 bytes; one special of 8 bytes.  Batches are sized from the measured use of every pool.
-constexpr uint64_t POOL_BYTES_PER_NODE = 116 + 51 + 40 + 8 + 8;
+// Pool shares.  With the GI and shadow rays traced in place a frame's nodes are the camera rays, reflection / refraction
+// children and the 1-in-10 GI rays that go on (scene.json: 21 M nodes, 16 M jobs -- one per colour node that is lit or
+// casts GI rays --, 7 M specials).  Per node: ray 64 + hit 28 + expansion info 16 + live 4 = 112 bytes; three quarters of
+// a job of 80 bytes; one special of 8 bytes (+ 8 of alignment slack).  Batches are sized from the measured use of every pool.
+constexpr uint64_t POOL_BYTES_PER_NODE = 112 + 60 + 8 + 8;
 
-// Carves the node, shadow and GI pools out of [mem, mem + bytes).  No allocation.
-int carve_pools(void *mem, uint64_t bytes, NodePool *np_out, ShadowPool *sp_out, GiPool *gp_out) {
+// Carves the node and job pools out of [mem, mem + bytes).  No allocation.
+int carve_pools(void *mem, uint64_t bytes, NodePool *np_out, GiPool *gp_out) {
     uint64_t cap = bytes / POOL_BYTES_PER_NODE;
     cap = std::min<uint64_t>(cap, 1ull << 30);
     cap &= ~uint64_t(255);
     if (cap < 4096) return fail(RT_ERR_NOMEM, "pool budget too small");
-    uint64_t scap = (cap + cap / 2) & ~uint64_t(255);
     char *p = static_cast<char *>(mem);
     auto take = [&](uint64_t n) {
         char *r = p;
@@ -379,19 +376,12 @@ int carve_pools(void *mem, uint64_t bytes, NodePool *np_out, ShadowPool *sp_out,
     np.prim = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.xinfo = reinterpret_cast<ExpandInfo *>(take(cap * 16));
     np.live = reinterpret_cast<uint32_t *>(take(cap * 4));
-    np.gi_job = reinterpret_cast<uint32_t *>(take(cap * 4));
     np.capacity = static_cast<uint32_t>(cap);
     GiPool &gp = *gp_out;
-    gp.job_capacity = static_cast<uint32_t>((cap / 2) & ~uint64_t(255));
+    gp.job_capacity = static_cast<uint32_t>((cap / 4 * 3) & ~uint64_t(255));
     gp.special_capacity = static_cast<uint32_t>(cap);
     gp.jobs = reinterpret_cast<GiJob *>(take(static_cast<uint64_t>(gp.job_capacity) * sizeof(GiJob)));
     gp.specials = reinterpret_cast<GiSpecial *>(take(static_cast<uint64_t>(gp.special_capacity) * sizeof(GiSpecial)));
-    ShadowPool &sp = *sp_out;
-    sp.s0 = reinterpret_cast<Vec2d *>(take(scap * 16));
-    sp.s1 = reinterpret_cast<Vec2d *>(take(scap * 16));
-    sp.light = reinterpret_cast<uint8_t *>(take(scap));
-    sp.occluded = reinterpret_cast<uint8_t *>(take(scap));
-    sp.capacity = static_cast<uint32_t>(scap);
     if (static_cast<uint64_t>(p - static_cast<char *>(mem)) > bytes) return fail(RT_ERR_NOMEM, "internal: pool carve exceeds budget");
     return RT_OK;
 }
@@ -411,7 +401,7 @@ int ensure_pools(rt_scene *s) {
     if (want < (1ull << 20)) return fail(RT_ERR_NOMEM, "less than 1 MiB of device memory free for the wavefront pools");
     HIP_TRY(hipMalloc(&s->pool_mem, want));
     s->pool_mem_bytes = s->pool_bytes;  // the budget this allocation answers (may be clamped)
-    if (int rc = carve_pools(s->pool_mem, want, &ctx.np, &ctx.sp, &ctx.gp)) return rc;
+    if (int rc = carve_pools(s->pool_mem, want, &ctx.np, &ctx.gp)) return rc;
     if (!ctx.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx.d_ctr), MAX_SHARDS * sizeof(Counters)));
     if (!ctx.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx.h_ctr), MAX_SHARDS * sizeof(Counters)));
     ctx.forget_estimates();
@@ -599,7 +589,6 @@ Shards plan_shards(const RenderCtx &c, uint64_t n, uint32_t ns) {
     sh.count = k;
     if (k == 1) sh.granule = ns;  // no padding items in small batches
     sh.node_cap = c.np.capacity / k;
-    sh.shadow_cap = c.sp.capacity / k;
     sh.job_cap = c.gp.job_capacity / k;
     sh.special_cap = c.gp.special_capacity / k;
     return sh;
@@ -616,7 +605,6 @@ Shards single_shard(const RenderCtx &c) {
     Shards sh{};
     sh.count = 1u;
     sh.node_cap = c.np.capacity;
-    sh.shadow_cap = c.sp.capacity;
     sh.job_cap = c.gp.job_capacity;
     sh.special_cap = c.gp.special_capacity;
     sh.granule = 1u;
@@ -659,7 +647,7 @@ int scratch_for_device(int device, void **out) {
         c.d_tiles_cap = SCRATCH_MAX_TILES;
         c.can_grow = false;
         c.h_ctr = f.h_ctr;
-        if (int rc = carve_pools(base + SCRATCH_CTR_BYTES + SCRATCH_TILE_BYTES, SCRATCH_POOL_BYTES, &c.np, &c.sp, &c.gp)) return rc;
+        if (int rc = carve_pools(base + SCRATCH_CTR_BYTES + SCRATCH_TILE_BYTES, SCRATCH_POOL_BYTES, &c.np, &c.gp)) return rc;
         f.ptr = ptr;
     }
     *out = f.ptr;
@@ -995,7 +983,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     {   // top of the tree kept in LDS by the traversal kernels: as many nodes as fit next to the per-lane stacks
         // without costing a block per CU (four 256-thread blocks share 160 KB), at most 512 (16 KB)
         const uint32_t stack_bytes = (static_cast<uint32_t>(sc->bvh_depth) + 2u) * BLOCK * static_cast<uint32_t>(sizeof(uint32_t));
-        const uint32_t budget = 40u * 1024u - 2048u;  // per block; 2 KB for the kernels' static LDS (work map, live-list masks)
+        const uint32_t budget = 40u * 1024u - 3072u;  // per block; 3 KB for the kernels' static LDS (work map; k_trace_shadow's prefix sums and result words)
         const uint32_t fit = stack_bytes < budget ? (budget - stack_bytes) / static_cast<uint32_t>(sizeof(BvhNode)) : 0u;
         dev.n_top_nodes = static_cast<uint32_t>(std::min<size_t>(n_built_nodes, std::min(fit, 512u)));
         uint32_t left = fit - dev.n_top_nodes;
@@ -1125,7 +1113,7 @@ int rt_scene_info(rt_scene *scene, uint64_t *out8) {
     out8[4] = scene->dev.n_bounded;
     out8[5] = scene->dev.n_planes;
     out8[6] = scene->ctx.np.capacity;
-    out8[7] = scene->ctx.sp.capacity;
+    out8[7] = scene->ctx.gp.job_capacity;
     return RT_OK;
 }
 
@@ -1147,7 +1135,6 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     const bool count_work = params && (params->flags & RT_FLAG_COUNT_WORK);
     const uint32_t max_depth = s->dev.opts.max_depth;
     const NodePool &np = ctx.np;
-    const ShadowPool &sp = ctx.sp;
     const GiPool &gp = ctx.gp;
     Counters *d_ctr = ctx.d_ctr;
 
@@ -1175,7 +1162,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     }
 
     uint64_t item0 = 0;
-    double call_max[4] = {0.0, 0.0, 0.0, 0.0};  // nodes, shadow rays, GI jobs, GI specials per camera ray: the largest of the call's batches
+    double call_max[3] = {0.0, 0.0, 0.0};  // nodes, jobs, GI specials per camera ray: the largest of the call's batches
     // first batch: modest guess, later batches sized from the measured expansion
     uint64_t batch = first_batch_items(ctx, plan.total_items, wl.ns);
     const uint32_t gmax = static_cast<uint32_t>(s->n_cus) * 8u;
@@ -1222,8 +1209,8 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
                 timer.begin(CLS_EXPAND);
                 hipLaunchKernelGGL(k_build_live, dim3(level == 0 ? shard_grid(s, sh, n / 4 + 1, 8) : g_wide), dim3(BLOCK), 0, stream, np, d_ctr, sh, level);
                 const uint32_t ge = level == 0 ? shard_grid(s, sh, n, 8) : g_wide;
-                if (count_work) hipLaunchKernelGGL(k_expand<true>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, gp, d_ctr, sh, level);
-                else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, sp, gp, d_ctr, sh, level);
+                if (count_work) hipLaunchKernelGGL(k_expand<true>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, gp, d_ctr, sh, level);
+                else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, gp, d_ctr, sh, level);
                 timer.end();
                 if (level + 1 < max_depth && gi_rays_host(s->dev.opts, level) <= GI_MAX_INPLACE) {  // the GI rays of this level's hits, in place
                     timer.begin(CLS_GI);
@@ -1238,16 +1225,14 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
                 timer.end();
             }
             timer.begin(CLS_SHADOW);
-            if (count_work)
-                hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, d_ctr, sh, 0u, stack_entries(s));
-            else
-                hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, sp, d_ctr, sh, 0u, stack_entries(s));
+            if (count_work) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, gp, d_ctr, sh, stack_entries(s));
+            else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, gp, d_ctr, sh, stack_entries(s));
             timer.end();
             for (uint32_t level = max_depth; level-- > 0;) {
                 timer.begin(CLS_RESOLVE);
                 const dim3 gr(level == 0 ? shard_grid(s, sh, n, 8) : g_wide);
-                if (level > 0) hipLaunchKernelGGL(k_resolve<true>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, gp, d_ctr, sh, level, 0u);  // camera rays are colour nodes
-                hipLaunchKernelGGL(k_resolve<false>, gr, dim3(BLOCK), 0, stream, s->dev, np, sp, gp, d_ctr, sh, level, aov);
+                if (level > 0) hipLaunchKernelGGL(k_resolve<true>, gr, dim3(BLOCK), 0, stream, s->dev, np, gp, d_ctr, sh, level, 0u);  // camera rays are colour nodes
+                hipLaunchKernelGGL(k_resolve<false>, gr, dim3(BLOCK), 0, stream, s->dev, np, gp, d_ctr, sh, level, aov);
                 timer.end();
             }
             timer.begin(CLS_ACCUM);
@@ -1263,7 +1248,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
             const Counters &ck = ctx.h_ctr[k];
             for (uint32_t l = 0; l <= MAX_LEVELS; ++l) c.level_count[l] += ck.level_count[l];
             c.node_alloc += ck.node_alloc;
-            c.shadow_alloc += ck.shadow_alloc;
+            c.shadow_rays += ck.shadow_rays;
             c.job_alloc += ck.job_alloc;
             c.special_alloc += ck.special_alloc;
             c.gi_rays += ck.gi_rays;
@@ -1312,7 +1297,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         closest += c.gi_rays - c.gi_materialised;  // GI rays traced in place; the ones that got a node are in level_count already
         if (max_depth == 0) closest = 0;
         st.closest_rays += closest;
-        st.shadow_rays += c.shadow_alloc;
+        st.shadow_rays += c.shadow_rays;
         st.camera_rays += c.active_camera;
         st.nodes_visited_closest += c.nodes_visited_closest;
         st.prims_tested_closest += c.prims_tested_closest;
@@ -1343,21 +1328,18 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         // provoke an overflow + re-run at the start of the next frame
         const double dn = static_cast<double>(n);
         call_max[0] = std::max(call_max[0], static_cast<double>(c.node_alloc) / dn);
-        call_max[1] = std::max(call_max[1], static_cast<double>(c.shadow_alloc) / dn);
-        call_max[2] = std::max(call_max[2], static_cast<double>(c.job_alloc) / dn);
-        call_max[3] = std::max(call_max[3], static_cast<double>(c.special_alloc) / dn);
+        call_max[1] = std::max(call_max[1], static_cast<double>(c.job_alloc) / dn);
+        call_max[2] = std::max(call_max[2], static_cast<double>(c.special_alloc) / dn);
         ctx.est_nodes_per_item = std::max(ctx.est_nodes_per_item, call_max[0]);
-        ctx.est_shadows_per_item = std::max(ctx.est_shadows_per_item, call_max[1]);
-        ctx.est_jobs_per_item = std::max(ctx.est_jobs_per_item, call_max[2]);
-        ctx.est_specials_per_item = std::max(ctx.est_specials_per_item, call_max[3]);
+        ctx.est_jobs_per_item = std::max(ctx.est_jobs_per_item, call_max[1]);
+        ctx.est_specials_per_item = std::max(ctx.est_specials_per_item, call_max[2]);
         batch = std::max<uint64_t>(wl.ns, static_cast<uint64_t>(0.7 * ctx.fit_items()));
         item0 += n;
     }
     if (call_max[0] > 0.0) {  // forget stale maxima of earlier calls (other windows / shards)
         ctx.est_nodes_per_item = call_max[0];
-        ctx.est_shadows_per_item = call_max[1];
-        ctx.est_jobs_per_item = call_max[2];
-        ctx.est_specials_per_item = call_max[3];
+        ctx.est_jobs_per_item = call_max[1];
+        ctx.est_specials_per_item = call_max[2];
     }
     if (gi_tuning && !count_work && st.retries == 0 && gi_rays_call >= 1000000u && gi_ms > 0.0) {
         GiTune &t = s->gi_tune;
@@ -1610,8 +1592,7 @@ int rt_trace_rays(rt_scene *s, uint32_t n, const double *origin, const double *d
             hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, nullptr, ctx.d_ctr, one, m);
             if (shadow) {
                 HIP_TRY(hipMemcpy(np.t, tmax + done, m * sizeof(double), hipMemcpyHostToDevice));
-                hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, ctx.sp, ctx.d_ctr, one,
-                                   m, stack_entries(s));
+                hipLaunchKernelGGL(k_trace_shadow_probe, dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, m, stack_entries(s));
             } else {
                 hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid_for(s, m, 4)), dim3(BLOCK), stack_lds_bytes(s), nullptr, s->dev, np, ctx.d_ctr, one, 0u,
                                    stack_entries(s));

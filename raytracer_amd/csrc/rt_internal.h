@@ -164,23 +164,32 @@ struct alignas(16) Vec2d {
     double x, y;
 };
 struct alignas(16) ExpandInfo {
-    uint32_t first_child, first_shadow;
-    uint32_t counts;      // nR | nT << 16 | nG << 17
+    uint32_t first_child;
+    uint32_t job;         // the colour node's ShadeJob (its shadow rays and, in place, its GI rays); NO_JOB: none
+    uint32_t counts;      // nR | nT << 16 | nG << 17; bit 31: the GI rays are the job's (traced in place)
     uint32_t light_mask;  // point lights that cast a shadow ray
 };
-// GI rays in place (compute_global_illumination, raytracing_scene.rs:98-133).  3 of 4 closest-hit rays of a frame are GI
-// rays and 9 of 10 of those end at once (a miss, or a surface whose get_illumination gathers nothing), so they get no
-// node record: k_expand leaves ONE job per colour node -- what is needed to draw its G(d) hemisphere rays -- and
-// k_trace_gi generates, traces and reduces them per job.  What a parent needs back: how many rays were unoccluded, and
-// -- in slot order, so that the f64 sum of :121 keeps its order -- the few rays whose emissive contribution is not zero:
-// a terminal hit on an emissive surface (kind 0: primitive id) or a hit that needs shading of its own and got a node
-// (kind 1: node index, resolved one level down before the parent reads it).
+constexpr uint32_t NO_JOB = 0xFFFFFFFFu;
+// Rays in place.  The rays a colour node's shading casts from its hit point and that end at once are never stored as
+// rays: k_expand leaves ONE job per colour node -- the hit point, the normal, the RNG key -- and the trace kernels
+// generate, trace and reduce them per job.
+//   * GI rays (compute_global_illumination, raytracing_scene.rs:98-133): 3 of 4 closest-hit rays of a frame, and 9 of 10
+//     of those end at once (a miss, or a surface whose get_illumination gathers nothing).  k_trace_gi draws the G(d)
+//     hemisphere rays of every job.  What a parent needs back: how many rays were unoccluded, and -- in slot order, so
+//     that the f64 sum of :121 keeps its order -- the few rays whose emissive contribution is not zero: a terminal hit
+//     on an emissive surface (kind 0: primitive id) or a hit that needs shading of its own and got a node (kind 1:
+//     node index, resolved one level down before the parent reads it).
+//   * shadow rays (:216-225, :428-437): one per point light on whose side the surface lies (`light_mask`), from the
+//     light to the hit point.  k_trace_shadow derives each from (light, P) and leaves one bit per light.
 struct alignas(16) GiJob {
     double P[3], n[3];  // hit point, shading normal
     uint64_t path;      // the parent's RNG path
     uint32_t root;      // camera-ray item
-    uint32_t pixel, sample;
-    uint32_t unoccluded, n_special, first_special;  // results
+    uint32_t pixel;
+    uint32_t sample_gi;  // bits 0..15 sample index; results of k_trace_gi: bits 16..23 unoccluded rays, bits 24..31 special rays
+    uint32_t first_special;    // result of k_trace_gi
+    uint32_t light_mask;       // point lights (index among the point lights) that get a shadow ray
+    uint32_t shadow_occluded;  // result of k_trace_shadow: the lights of light_mask whose ray was stopped
 };
 static_assert(sizeof(GiJob) == 80, "GiJob must be 80 bytes");
 struct GiSpecial {
@@ -188,6 +197,9 @@ struct GiSpecial {
     uint32_t id;         // kind 0: primitive id (terminal hit, emissive surface); kind 1: node index
 };
 constexpr uint32_t GI_MAX_INPLACE = 64;  // G(d) above a wave's width: the rays are materialised as nodes (the round-1 path)
+constexpr uint32_t job_sample(uint32_t sample_gi) { return sample_gi & 0xFFFFu; }  // constexpr: host and device code alike
+constexpr uint32_t job_unoccluded(uint32_t sample_gi) { return (sample_gi >> 16) & 0xFFu; }
+constexpr uint32_t job_n_special(uint32_t sample_gi) { return sample_gi >> 24; }
 struct GiPool {
     GiJob *jobs;
     GiSpecial *specials;
@@ -207,14 +219,6 @@ struct NodePool {
     // by the trace kernel into the level's own index range of this array -- colour nodes from the range's start
     // upwards, illumination nodes from its end downwards (Counters::live_colour / live_illum count them).
     uint32_t *live;
-    uint32_t *gi_job;  // colour nodes whose GI rays are traced in place: index of their GiJob
-    uint32_t capacity;
-};
-
-struct ShadowPool {
-    Vec2d *s0, *s1;     // (d.x, d.y) (d.z, tmax); the origin is the light's position
-    uint8_t *light;     // index among point lights
-    uint8_t *occluded;  // result
     uint32_t capacity;
 };
 
@@ -223,7 +227,7 @@ struct Counters {
     uint32_t level_start[MAX_LEVELS + 1];
     uint32_t level_count[MAX_LEVELS + 1];
     unsigned long long node_alloc;    // bump pointer into the node pool
-    unsigned long long shadow_alloc;  // bump pointer into the shadow pool
+    unsigned long long shadow_rays;   // shadow rays traced (k_trace_shadow; statistics)
     unsigned long long job_alloc;      // bump pointer into the shard's GI jobs
     unsigned long long special_alloc;  // bump pointer into the shard's GI specials
     uint32_t job_level_start[MAX_LEVELS + 1];  // jobs left by k_expand(level): [job_level_start[level], job_alloc) until the level is closed
@@ -256,7 +260,6 @@ constexpr uint32_t MAX_SHARDS = 64;
 struct Shards {
     uint32_t count;
     uint32_t node_cap;    // nodes per shard
-    uint32_t shadow_cap;  // shadow rays per shard
     uint32_t job_cap;     // GI jobs per shard
     uint32_t special_cap; // GI specials per shard
     uint32_t granule;     // camera-ray items per deal (multiple of the samples per pixel)

@@ -54,7 +54,7 @@ __device__ __forceinline__ void item_to_pixel(const WorkList &wl, uint32_t item,
 
 struct ShardCtx {
     Counters *ctr;
-    uint32_t node_off, shadow_off;  // first pool index of the shard
+    uint32_t node_off;              // first pool index of the shard
     uint32_t job_off, special_off;
     uint32_t bid, nblocks;          // this block's index / the block count within the shard
     uint32_t shard;
@@ -65,7 +65,6 @@ __device__ __forceinline__ ShardCtx shard_ctx(Counters *ctrs, const Shards &sh) 
     c.shard = blockIdx.x % sh.count;
     c.ctr = ctrs + c.shard;
     c.node_off = c.shard * sh.node_cap;
-    c.shadow_off = c.shard * sh.shadow_cap;
     c.job_off = c.shard * sh.job_cap;
     c.special_off = c.shard * sh.special_cap;
     c.bid = blockIdx.x / sh.count;
@@ -91,15 +90,16 @@ struct LevelMap {
     uint32_t dead;                    // some shard overflowed: the batch will be re-run, do nothing
 };
 // All threads of the block call it (one __syncthreads inside); returns the number of groups.
+// job_list: the entries are the jobs of all levels (k_trace_shadow) instead of the nodes of `level`.
 __device__ __forceinline__ uint32_t level_map_build(LevelMap &m, const Counters *ctrs, const Shards &sh, uint32_t level,
-                                                   bool shadow_list) {
+                                                   bool job_list) {
     if (threadIdx.x < 64u) {
         const uint32_t k = threadIdx.x;
         uint32_t cnt = 0, over = 0;
         if (k < sh.count) {
-            cnt = shadow_list ? static_cast<uint32_t>(ctrs[k].shadow_alloc) : ctrs[k].level_count[level];
+            cnt = job_list ? static_cast<uint32_t>(ctrs[k].job_alloc) : ctrs[k].level_count[level];
             over = ctrs[k].overflow;
-            m.base[k] = shadow_list ? k * sh.shadow_cap : k * sh.node_cap + ctrs[k].level_start[level];
+            m.base[k] = job_list ? k * sh.job_cap : k * sh.node_cap + ctrs[k].level_start[level];
             m.count[k] = cnt;
         }
         uint32_t x = (cnt + 63u) / 64u;
@@ -201,6 +201,15 @@ __device__ __forceinline__ uint64_t wave_alloc(unsigned long long *counter, uint
     base = __shfl(base, 63, 64);
     *wave_total = total;
     return base + x - n;
+}
+
+// first p in [0,64) with incl[p] > j (incl = inclusive prefix sums of one wave)
+__device__ __forceinline__ uint32_t wave_owner(const uint32_t *incl, uint32_t j) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 32; step >= 1; step >>= 1)
+        if (incl[lo + step - 1] <= j) lo += step;
+    return lo;
 }
 
 __device__ __forceinline__ uint32_t ipow(uint32_t b, uint32_t e) {
@@ -325,7 +334,7 @@ __global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
     for (uint32_t i = 0; i <= MAX_LEVELS; ++i) ctr->live_colour[i] = ctr->live_illum[i] = 0;
     ctr->level_count[0] = local;  // items past n_items are padding (META_INACTIVE)
     ctr->node_alloc = local;
-    ctr->shadow_alloc = 0;
+    ctr->shadow_rays = 0;
     ctr->job_alloc = 0;
     ctr->special_alloc = 0;
     for (uint32_t i = 0; i <= MAX_LEVELS; ++i) ctr->job_level_start[i] = 0;
@@ -346,7 +355,7 @@ __global__ void k_advance_level(Counters *ctrs, Shards sh, uint32_t level) {
     if (blockIdx.x != 0 || k >= sh.count) return;
     Counters *ctr = ctrs + k;
     uint32_t start = ctr->level_start[level] + ctr->level_count[level];
-    if (ctr->node_alloc > sh.node_cap || ctr->shadow_alloc > sh.shadow_cap || ctr->job_alloc > sh.job_cap || ctr->special_alloc > sh.special_cap)
+    if (ctr->node_alloc > sh.node_cap || ctr->job_alloc > sh.job_cap || ctr->special_alloc > sh.special_cap)
         ctr->overflow = 1;
     ctr->job_level_start[level + 1] = static_cast<uint32_t>(ctr->job_alloc);  // k_expand(level + 1) appends from here
     ctr->level_start[level + 1] = start;
@@ -893,7 +902,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
             const GiJob &job = gp.jobs[job_index];
             const d3 P = mk3(job.P[0], job.P[1], job.P[2]), n = mk3(job.n[0], job.n[1], job.n[2]);
             double u1, u2;
-            rng_pair(wl.seed, job.pixel, job.sample, path_child(job.path, SLOT_GI + slot), &u1, &u2);
+            rng_pair(wl.seed, job.pixel, job_sample(job.sample_gi), path_child(job.path, SLOT_GI + slot), &u1, &u2);
             ray.d = sample_direction(SAMPLE_HEMISPHERE, n, 0.0, u1, u2);
             ray.o = P + ray.d * BIAS;  // :115
             if (two_phase) {  // closest special hit, then: does anything precede it / lie within the occlusion distance?
@@ -952,8 +961,8 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
                 GiSpecial{slot | (wants_node ? 0x80000000u : 0u), wants_node ? node_index : hit_id};
         if (valid && slot == 0) {  // the job's results
             GiJob &job = gp.jobs[job_index];
-            job.unoccluded = static_cast<uint32_t>(__popcll(m_unocc & job_mask));
-            job.n_special = static_cast<uint32_t>(__popcll(m_special & job_mask));
+            job.sample_gi = job_sample(job.sample_gi) | (static_cast<uint32_t>(__popcll(m_unocc & job_mask)) << 16) |
+                            (static_cast<uint32_t>(__popcll(m_special & job_mask)) << 24);
             job.first_special = special_off + static_cast<uint32_t>(__popcll(m_special & ((1ull << (jl * G)) - 1ull)));
         }
     }
@@ -1024,89 +1033,144 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_illum_last(SceneDev sc, 
     }
 }
 
-// KdTreeAccelerator::shadow_cast semantics: OR over primitives within max_distance.
-// PROBE: rays come from the node pool (rt_trace_rays) instead of the shadow pool.
-template <bool COUNT, bool PROBE>
-__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc, NodePool np, ShadowPool sp_pool, Counters *ctrs,
-                                                       Shards shards, uint32_t probe_count, uint32_t stack_entries) {
+// KdTreeAccelerator::shadow_cast (bounds.rs:310-316, :366-399) for one ray: OR over the primitives within max_distance,
+// the unbounded objects first.
+template <bool COUNT>
+__device__ __forceinline__ bool any_hit(const SceneDev &sc, const TreeView &tv, uint32_t *stack, const RayD &ray, double tmax,
+                                        unsigned long long &n_nodes, unsigned long long &n_prims) {
+    bool occluded = false;
+    for (uint32_t p = 0; p < sc.n_planes && !occluded; ++p) {
+        const PlanePrim pl = sc.planes[p];
+        const double *inv = sc.inv_world + 12ull * (pl.meta >> 4);
+        RayD orr;
+        orr.o = xf_point(inv, ray.o);
+        orr.d = xf_vector(inv, ray.d);
+        HitRec h;
+        if (COUNT) n_prims++;
+        if (hit_plane(mk3(pl.normal[0], pl.normal[1], pl.normal[2]), (pl.meta >> 2) & 3u, true, orr, true, tmax, &h) && h.t <= tmax) occluded = true;
+    }
+    if (!occluded && tv.root_ref != 0xFFFFFFFFu) {
+        const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
+        const float limit = cull_limit_f32(cull_limit(tmax));
+        ObjRayCache cache;
+        cache.xf = 0xFFFFFFFFu;
+        stack[0] = STACK_SENTINEL;
+        uint32_t sp = 1;
+        uint32_t cur = tv.root_ref;
+        while (true) {
+            cur = descend<COUNT>(tv, cr, limit, cur, stack, sp, n_nodes);
+            if (cur == STACK_SENTINEL) break;
+            const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t k = 0; k < n && !occluded; ++k) {
+                HitRec h;
+                if (COUNT) n_prims++;
+                uint32_t pid;
+                if (test_leaf_prim<true>(sc, tv.leaf_prims + first + k, ray, cache, tmax, &h, &pid)) occluded = true;
+            }
+            if (occluded) break;
+            cur = stack[(--sp) * BLOCK];
+        }
+    }
+    return occluded;
+}
+
+// Shadow rays in place (get_color_phong :216-225, get_color_physical :428-437: from the light towards the surface,
+// shadow_cast(.., distance - BIAS), :94-96).  A shadow ray is (light, hit point): k_expand leaves the hit point and the
+// mask of the point lights on whose side the surface lies in the colour node's job, and this kernel derives, traces and
+// reduces the rays of ALL levels' jobs in one launch -- no ray record is written or read (before: 34 bytes per ray out
+// of k_expand, in here, and a result byte each into k_resolve).  A wave takes 64 jobs a round and deals their rays to
+// its lanes densely (prefix sums of the masks' bit counts, the owner of ray j by binary search as in k_expand), so
+// every lane starts with a ray whatever the masks hold; a stopped ray sets its light's bit in the job's word through
+// LDS, and the job's lane stores the word.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc, GiPool gp, Counters *ctrs, Shards shards, uint32_t stack_entries) {
     extern __shared__ __align__(16) uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;
     __shared__ LevelMap map;
+    __shared__ uint32_t s_incl[BLOCK], s_occ[BLOCK];
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
-    const uint32_t n_groups = PROBE ? (probe_count + 63u) / 64u : level_map_build(map, ctrs, shards, 0u, true);
+    const uint32_t n_groups = level_map_build(map, ctrs, shards, 0u, true);
     if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
     const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
+    const TreeView tree = main_tree(sc, top_nodes);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
     unsigned long long n_nodes = 0, n_prims = 0;
-    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
-        uint32_t n_valid, i;
-        if (PROBE) {  // single-shard launch: rays 0..probe_count of the node pool
-            i = g * 64u;
-            n_valid = min(64u, probe_count - i);
-        } else {
-            i = level_map_group(map, shards, g, &n_valid);
+    uint32_t wave_rays = 0;  // wave-uniform
+    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (tid >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
+        uint32_t n_valid;
+        const uint32_t first_job = level_map_group(map, shards, g, &n_valid);
+        const bool valid = lane < n_valid;
+        const uint32_t mask = valid ? gp.jobs[first_job + lane].light_mask : 0u;
+        uint32_t incl = static_cast<uint32_t>(__popc(mask));
+#pragma unroll
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += y;
         }
-        i += threadIdx.x & 63u;
-        if ((threadIdx.x & 63u) >= n_valid) continue;
-        RayD ray;
-        double tmax;
-        if (PROBE) {
-            load_ray(np, i, &ray.o, &ray.d);
-            tmax = np.t[i];
-        } else {
-            const DLight &l = sc.lights[sp_pool.light[i]];
-            ray.o = mk3(l.position[0], l.position[1], l.position[2]);
-            const Vec2d a = sp_pool.s0[i], b = sp_pool.s1[i];
-            ray.d = mk3(a.x, a.y, b.x);
-            tmax = b.y;
-        }
-        bool occluded = false;
-        for (uint32_t p = 0; p < sc.n_planes && !occluded; ++p) {
-            const PlanePrim pl = sc.planes[p];
-            const double *inv = sc.inv_world + 12ull * (pl.meta >> 4);
-            RayD orr;
-            orr.o = xf_point(inv, ray.o);
-            orr.d = xf_vector(inv, ray.d);
-            HitRec h;
-            if (COUNT) n_prims++;
-            if (hit_plane(mk3(pl.normal[0], pl.normal[1], pl.normal[2]), (pl.meta >> 2) & 3u, true, orr, true, tmax,
-                          &h) &&
-                h.t <= tmax)
-                occluded = true;
-        }
-        if (!occluded && sc.root_ref != 0xFFFFFFFFu) {
-            const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
-            const float limit = cull_limit_f32(cull_limit(tmax));
-            ObjRayCache cache;
-            cache.xf = 0xFFFFFFFFu;
-            stack[0] = STACK_SENTINEL;
-            uint32_t sp = 1;
-            uint32_t cur = sc.root_ref;
-            while (true) {
-                cur = descend<COUNT>(main_tree(sc, top_nodes), cr, limit, cur, stack, sp, n_nodes);
-                if (cur == STACK_SENTINEL) break;
-                const uint32_t first = cur & 0x0FFFFFFFu, n = ((cur >> 28) & 7u) + 1u;
-                for (uint32_t k = 0; k < n && !occluded; ++k) {
-                    HitRec h;
-                    if (COUNT) n_prims++;
-                    uint32_t pid;
-                    if (test_leaf_prim<true>(sc, sc.leaf_prims + first + k, ray, cache, tmax, &h, &pid)) occluded = true;
-                }
-                if (occluded) break;
-                cur = stack[(--sp) * BLOCK];
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (total == 0) continue;  // wave-uniform
+        wave_rays += total;
+        s_incl[tid] = incl;
+        s_occ[tid] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the LDS stores above -> the reads below (same wave)
+        for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t j = min(base + lane, total - 1u);
+            const bool active = base + lane < total;
+            const uint32_t p = wave_owner(s_incl + wbase, j);  // the job (lane index) ray j belongs to
+            const uint32_t pm = __shfl(mask, p, 64);
+            if (!active) continue;
+            const uint32_t slot = j - (s_incl[wbase + p] - static_cast<uint32_t>(__popc(pm)));
+            uint32_t mm = pm;  // slot-th set bit of the job's light mask -> index among the point lights
+            for (uint32_t k = 0; k < slot; ++k) mm &= mm - 1u;
+            const uint32_t want = static_cast<uint32_t>(__ffs(mm)) - 1u;
+            uint32_t li = 0, seen = 0;
+            for (; li < sc.n_lights; ++li) {
+                if (sc.lights[li].kind != RT_LIGHT_POINT) continue;
+                if (seen == want) break;
+                seen++;
             }
+            const DLight &l = sc.lights[li];
+            const double *Pp = gp.jobs[first_job + p].P;
+            RayD ray;
+            ray.o = mk3(l.position[0], l.position[1], l.position[2]);
+            d3 ld = ray.o - mk3(Pp[0], Pp[1], Pp[2]);
+            const double dist = length3(ld);
+            ld = unit3(ld);
+            ray.d = -ld;
+            if (any_hit<COUNT>(sc, tree, stack, ray, dist - BIAS, n_nodes, n_prims)) atomicOr(&s_occ[wbase + p], 1u << want);
         }
-        if (PROBE) np.prim[i] = occluded ? 1u : 0u;
-        else sp_pool.occluded[i] = occluded ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the LDS atomics -> the read below
+        if (mask) gp.jobs[first_job + lane].shadow_occluded = s_occ[tid];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... before the next round's stores
     }
+    if (lane == 0 && wave_rays) atomicAdd(&ctr->shadow_rays, static_cast<unsigned long long>(wave_rays));
     if (COUNT) {
         atomicAdd(&ctr->nodes_visited_shadow, n_nodes & ((1ull << 40) - 1ull));
         atomicAdd(&ctr->prims_tested_shadow, n_prims);
     }
 }
 
+// Any-hit probe rays of rt_trace_rays: rays 0..probe_count of the node pool (single-shard launch), limit in np.t.
+__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow_probe(SceneDev sc, NodePool np, uint32_t probe_count, uint32_t stack_entries) {
+    extern __shared__ __align__(16) uint32_t stack_lds[];
+    uint32_t *stack = stack_lds + threadIdx.x;
+    const uint32_t n_groups = (probe_count + 63u) / 64u;
+    if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
+    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
+    unsigned long long n_nodes = 0, n_prims = 0;
+    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
+        const uint32_t i = g * 64u + (threadIdx.x & 63u);
+        if (i >= probe_count) continue;
+        RayD ray;
+        load_ray(np, i, &ray.o, &ray.d);
+        np.prim[i] = any_hit<false>(sc, main_tree(sc, top_nodes), stack, ray, np.t[i], n_nodes, n_prims) ? 1u : 0u;
+    }
+}
+
 // ------------------------------------------------------------------ expand
-// Emits the child rays and shadow rays of every node of `level`.
-// Child block layout of a node: [reflection x nR][refraction x nT][GI x nG].
+// Emits the child rays of every node of `level`, and for a colour node the job that stands for its shadow rays and
+// GI rays (traced in place by k_trace_shadow / k_trace_gi).
+// Child block layout of a node: [reflection x nR][refraction x nT][GI x nG] (GI children only when G(d) > 64).
 //
 // Two phases per 64 parents (one wave):
 //   A  one parent per lane: compute_data, child / shadow-ray counts, wave-wide
@@ -1115,7 +1179,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
 //      parent by binary search over the wave's inclusive prefix sums, draws its
 //      own sample and stores its ray -> every store instruction writes 64
 //      consecutive records (phase A's per-parent loops wrote 64 strided ones and
-//      left lanes of missed rays idle).  Same for the shadow rays.
+//      left lanes of missed rays idle).
 // Child order (parent-major, slot-minor) and RNG keys are unchanged.
 // The nodes that still need work (not finished by the trace kernel, not padding) come from the level's live lists
 // (NodePool::live, LiveMap, k_build_live): every wave takes groups of 64 live nodes, so the heavy path has (nearly)
@@ -1130,21 +1194,11 @@ struct ExpandLds {
     uint32_t root[BLOCK], pixel[BLOCK], sample[BLOCK];
     uint32_t counts[BLOCK];                     // nR | nT << 16 | nG << 17 | phong << 31
     uint32_t meta_same[BLOCK], meta_refr[BLOCK];
-    uint32_t mask[BLOCK];                       // point lights that get a shadow ray
-    uint32_t incl_nodes[BLOCK], incl_shadows[BLOCK];
+    uint32_t incl_nodes[BLOCK];
 };
 
-// first p in [0,64) with incl[p] > j (incl = inclusive prefix sums of one wave)
-__device__ __forceinline__ uint32_t wave_owner(const uint32_t *incl, uint32_t j) {
-    uint32_t lo = 0;
-#pragma unroll
-    for (uint32_t step = 32; step >= 1; step >>= 1)
-        if (incl[lo + step - 1] <= j) lo += step;
-    return lo;
-}
-
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, WorkList wl, NodePool np, ShadowPool sp, GiPool gp, Counters *ctrs,
+__global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, WorkList wl, NodePool np, GiPool gp, Counters *ctrs,
                                                  Shards shards, uint32_t level) {
     __shared__ ExpandLds L;
     __shared__ LiveMap map;
@@ -1160,7 +1214,7 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
         const uint32_t node = live_map_node(map, shards, np.live, g, lane);
         const bool valid = node != 0xFFFFFFFFu;
         const uint32_t idx = valid ? node : 0u;
-        uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0, phong_flag = 0, nJ = 0;
+        uint32_t nR = 0, nT = 0, nG = 0, nS = 0, mask = 0, phong_flag = 0, nJ = 0, gi_job = 0;
         uint32_t prim = RT_NO_HIT, meta = 0;
         d3 job_P = mk3(0.0, 0.0, 0.0), job_n = mk3(0.0, 0.0, 0.0);
         if (valid) {
@@ -1196,11 +1250,9 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
                 }
             }
             if (!next_real) nR = nT = nG = 0;
-            if (gi_in_place && nG) {  // one job instead of nG child nodes
-                nJ = 1;
+            if (gi_in_place && nG) {  // the job instead of nG child nodes
+                gi_job = 0x80000000u;
                 nG = 0;
-                job_P = s.P;
-                job_n = s.n;
             }
             if (cast_shadows) {
                 uint32_t bit = 0;
@@ -1215,6 +1267,11 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
                     }
                     bit++;
                 }
+            }
+            if (gi_job || nS) {  // the colour node's job: its shadow rays and (gi_job) its GI rays
+                nJ = 1;
+                job_P = s.P;
+                job_n = s.n;
             }
             // ---- context for phase B
             L.Px[tid] = s.P.x;
@@ -1252,72 +1309,38 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
         if (COUNT && valid) {  // census of the nodes that reach the heavy path
             atomicAdd(&ctr->census[level][(meta & META_ILLUM) ? 1 : 0], 1ull);
             if (prim == RT_NO_HIT) atomicAdd(&ctr->census[level][2], 1ull);
-            if (total + nS == 0) atomicAdd(&ctr->census[level][3], 1ull);
+            if (total + nS + gi_job == 0) atomicAdd(&ctr->census[level][3], 1ull);
         }
         L.counts[tid] = nR | (nT << 16) | (nG << 17) | phong_flag;
-        L.mask[tid] = mask;
-        uint32_t wave_nodes, wave_shadows;
+        uint32_t wave_nodes, wave_jobs;
         const uint64_t child64 = wave_alloc(&ctr->node_alloc, total, &wave_nodes);
-        const uint64_t shadow64 = wave_alloc(&ctr->shadow_alloc, nS, &wave_shadows);
-        uint32_t wave_jobs = 0;
-        uint64_t job64 = 0;
-        if (gi_in_place && next_real) job64 = wave_alloc(&ctr->job_alloc, nJ, &wave_jobs);  // wave-uniform condition
+        const uint64_t job64 = wave_alloc(&ctr->job_alloc, nJ, &wave_jobs);
         // shard-local positions; wave-uniform overflow test (first lane's base + wave total)
-        const uint64_t node_local = __shfl(child64, 0, 64), shadow_local = __shfl(shadow64, 0, 64), job_local = __shfl(job64, 0, 64);
-        if (node_local + wave_nodes > shards.node_cap || shadow_local + wave_shadows > shards.shadow_cap || job_local + wave_jobs > shards.job_cap) {
+        const uint64_t node_local = __shfl(child64, 0, 64), job_local = __shfl(job64, 0, 64);
+        if (node_local + wave_nodes > shards.node_cap || job_local + wave_jobs > shards.job_cap) {
             if (lane == 0) atomicOr(&ctr->overflow, 1u);
             return;  // the shard is dead for this batch (wave-uniform exit)
         }
         const uint32_t node_base = c.node_off + static_cast<uint32_t>(node_local);
-        const uint32_t shadow_base = c.shadow_off + static_cast<uint32_t>(shadow_local);
         const uint32_t first_child = c.node_off + static_cast<uint32_t>(child64);
-        const uint32_t first_shadow = c.shadow_off + static_cast<uint32_t>(shadow64);
         L.incl_nodes[tid] = first_child - node_base + total;
-        L.incl_shadows[tid] = first_shadow - shadow_base + nS;
-        if (valid) {
-            np.xinfo[idx] = ExpandInfo{first_child, first_shadow, nR | (nT << 16) | (nJ ? 0x80000000u : (nG << 17)), mask};
-        }
-        if (nJ) {  // the job: what k_trace_gi needs to draw this node's GI rays
-            const uint32_t ji = c.job_off + static_cast<uint32_t>(job64);
-            np.gi_job[idx] = ji;
+        const uint32_t ji = nJ ? c.job_off + static_cast<uint32_t>(job64) : NO_JOB;
+        if (valid) np.xinfo[idx] = ExpandInfo{first_child, ji, nR | (nT << 16) | (nG << 17) | gi_job, mask};
+        if (nJ) {  // what k_trace_shadow / k_trace_gi need to derive this node's shadow and GI rays
             GiJob job;
             job.P[0] = job_P.x; job.P[1] = job_P.y; job.P[2] = job_P.z;
             job.n[0] = job_n.x; job.n[1] = job_n.y; job.n[2] = job_n.z;
             job.path = L.path[tid];
             job.root = L.root[tid];
             job.pixel = L.pixel[tid];
-            job.sample = L.sample[tid];
-            job.unoccluded = 0;
-            job.n_special = 0;
+            job.sample_gi = L.sample[tid];  // the results of k_trace_gi start as zero
             job.first_special = 0;
+            job.light_mask = mask;
+            job.shadow_occluded = 0;
             gp.jobs[ji] = job;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // phase A's LDS stores -> phase B's reads (same wave)
 
-        // ---- phase B: shadow rays, from the light towards the surface (:217-225, :429-437)
-        for (uint32_t j = lane; j < wave_shadows; j += 64u) {
-            const uint32_t p = wbase + wave_owner(L.incl_shadows + wbase, j);
-            const uint32_t pm = L.mask[p];
-            uint32_t slot = j - (L.incl_shadows[p] - static_cast<uint32_t>(__popc(pm)));
-            // slot-th set bit of the parent's light mask -> index among point lights
-            uint32_t mm = pm;
-            for (uint32_t k = 0; k < slot; ++k) mm &= mm - 1u;
-            const uint32_t want = static_cast<uint32_t>(__ffs(mm)) - 1u;
-            uint32_t li = 0, seen = 0;
-            for (; li < sc.n_lights; ++li) {
-                if (sc.lights[li].kind != RT_LIGHT_POINT) continue;
-                if (seen == want) break;
-                seen++;
-            }
-            const DLight &l = sc.lights[li];
-            d3 ld = mk3(l.position[0], l.position[1], l.position[2]) - mk3(L.Px[p], L.Py[p], L.Pz[p]);
-            const double dist = length3(ld);
-            ld = unit3(ld);
-            const uint32_t k = shadow_base + j;
-            sp.s0[k] = Vec2d{-ld.x, -ld.y};
-            sp.s1[k] = Vec2d{-ld.z, dist - BIAS};  // shadow_cast(.., max_distance - BIAS), :94-96
-            sp.light[k] = static_cast<uint8_t>(li);
-        }
         // ---- phase B: child rays
         for (uint32_t j = lane; j < wave_nodes; j += 64u) {
             const uint32_t p = wbase + wave_owner(L.incl_nodes + wbase, j);
@@ -1369,7 +1392,7 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
 // few multiplies) and colour nodes (the full shading; register heavy), so that the
 // illumination nodes do not run at the colour path's two waves per SIMD.
 template <bool ILLUM>
-__global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, ShadowPool sp, GiPool gp, Counters *ctrs, Shards shards,
+__global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES) void k_resolve(SceneDev sc, NodePool np, GiPool gp, Counters *ctrs, Shards shards,
                                                   uint32_t level, uint32_t aov) {
     __shared__ LiveMap map;
     const uint32_t n_groups = live_map_build(map, ctrs, shards, level, !ILLUM, ILLUM);
@@ -1428,10 +1451,13 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES)
                 }
             }
 
+            uint32_t shadow_occluded = 0;  // the job's other result: the lights of xi.light_mask whose shadow ray was stopped
+            if (!ILLUM && xi.job != NO_JOB) shadow_occluded = gp.jobs[xi.job].shadow_occluded;
             if (gi_job) {  // compute_global_illumination's sums from the job: the non-zero terms in slot order (:121), the count (:123-125)
-                const GiJob &job = gp.jobs[np.gi_job[idx]];
-                unoccluded = job.unoccluded;
-                const uint32_t ns = job.n_special, fs = job.first_special;
+                const GiJob &job = gp.jobs[xi.job];
+                const uint32_t res = job.sample_gi;
+                unoccluded = job_unoccluded(res);
+                const uint32_t ns = job_n_special(res), fs = job.first_special;
                 for (uint32_t q = 0; q < ns; ++q) {
                     const GiSpecial sp1 = gp.specials[fs + q];
                     if (sp1.slot_kind >> 31) {  // a node of its own, resolved one level down
@@ -1508,17 +1534,16 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES)
                 d3 ambient = mk3(0.0, 0.0, 0.0), irradiance = mk3(0.0, 0.0, 0.0);
                 if (m.kind == RT_MAT_PHYSICAL || m.reflectivity < 1.0) {
                     const uint32_t mask = xi.light_mask;
-                    uint32_t bit = 0, k = xi.first_shadow;
+                    uint32_t bit = 0;
                     for (uint32_t li = 0; li < sc.n_lights; ++li) {
                         const DLight &l = sc.lights[li];
                         if (l.kind == RT_LIGHT_AMBIENT) {
                             ambient = ambient + hadamard(mk3(l.color[0], l.color[1], l.color[2]), mc);
                             continue;
                         }
-                        const bool lit_side = (mask >> bit) & 1u;
+                        const bool lit_side = (mask >> bit) & 1u, occluded = (shadow_occluded >> bit) & 1u;
                         bit++;
                         if (!lit_side) continue;  // n.l <= 0 (decided in k_expand with the same arithmetic)
-                        const bool occluded = sp.occluded[k++] != 0;
                         if (occluded) continue;
                         d3 ld = mk3(l.position[0], l.position[1], l.position[2]) - s.P;
                         const double dist = length3(ld);

@@ -140,7 +140,7 @@ class DeviceScene:
     def info(self):
         out = (C.c_uint64 * 8)()
         _check(lib().rt_scene_info(self._h, out))
-        keys = ["bvh_nodes", "bvh_leaves", "bvh_depth", "scene_bytes", "bounded", "planes", "node_capacity", "shadow_capacity"]
+        keys = ["bvh_nodes", "bvh_leaves", "bvh_depth", "scene_bytes", "bounded", "planes", "node_capacity", "job_capacity"]
         return dict(zip(keys, [int(v) for v in out]))
 
     def bvh(self):
