@@ -164,9 +164,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # scene set-up, not a step: the library settles which variant of k_trace_gi is fastest on this scene during a scene's
-    # first render calls (an untimed one, one with its starting configuration, one per switch: six at most) (rt_api.hip GiTune; the frames are the same bit for bit)
-    for _ in range(6):
+    # scene set-up, not a step: the library settles which variant of the closest-hit kernels is fastest on this scene during
+    # the scene's first render calls (an untimed one, two with its starting configuration, two per switch: eleven at most;
+    # rt_tune.h GiTune; the frames are the same bit for bit)
+    for _ in range(11):
         step()
     for _ in range(args.warmup):
         step()
@@ -193,7 +194,7 @@ def main():
         out = {
             "metric": f"Mrays/sec (whole node) on {os.path.basename(args.scene)} {w}x{h} {spp}spp", "value": round(value, 3), "unit": "Mrays/s",
             "n_gpus": args.gpus if single_process_multi else world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if config_tag.endswith("procedural") else "scene file (the reference's own scenes/ input)",
             "config": {
                 "workload": f"{os.path.basename(args.scene)} {w}x{h} {spp}spp, {scene.n_prims} primitives, "
                             f"{rays // max(1, args.steps)} rays/frame ({config_tag}); scene resident in HBM, frame reduced to rank 0",

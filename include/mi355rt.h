@@ -209,7 +209,8 @@ typedef struct rt_scene rt_scene; /* opaque */
 int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
 void rt_scene_destroy(rt_scene *scene);
 
-/* Limit the device memory used for wavefront pools (default 24 GiB, allocated at the first render). */
+/* Limit the device memory used for wavefront pools (allocated at the first render).  Default: sized from the frame -- 64
+ * node slots per camera ray of width x height x samples, at least 256 MiB, at most 24 GiB; a budget set here is taken as it is. */
 int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes);
 
 /* Replaces the pixel loop of raytrace_to_image

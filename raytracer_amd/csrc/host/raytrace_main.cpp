@@ -122,11 +122,12 @@ int main(int argc, char **argv) {
     std::printf("Took %.6fs to render the scene.\n", dt);
     std::printf("%llu rays, %.1f Mrays/s (kernels %.3f ms)\n", static_cast<unsigned long long>(rays),
                 static_cast<double>(rays) / dt / 1e6, stats.ms_total);
+    t0 = std::chrono::steady_clock::now();
     if (rth_write_png(output, desc->opts.width, desc->opts.height, rgba.data()) != RT_OK) {
         std::fprintf(stderr, "unable to write image\n");
         return 1;
     }
-    std::printf("Output written to %s in %.3fs\n", output, total);
+    std::printf("Output written to %s in %.3fs (+ %.1f ms to encode and write the PNG)\n", output, total, 1e3 * seconds_since(t0));
     rt_scene_destroy(scene);
     rth_scene_free(hs);
     return 0;

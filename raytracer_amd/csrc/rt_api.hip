@@ -162,7 +162,9 @@ int upload(Stager &st, const T *host, size_t count, const T **dev, std::vector<v
     HIP_TRY(hipMalloc(&p, count * sizeof(T)));
     st.ms_alloc += Stager::since(t0);
     allocs.push_back(p);
+    const auto t1 = std::chrono::steady_clock::now();
     if (int rc = st.copy(p, host, count * sizeof(T))) return rc;
+    if (std::getenv("MI355RT_TIMING")) std::fprintf(stderr, "rt_scene_create:   upload of %zu bytes: hipMalloc %.2f ms, copy %.2f ms\n", count * sizeof(T), std::chrono::duration<double, std::milli>(t1 - t0).count(), Stager::since(t1));
     *dev = static_cast<const T *>(p);
     *bytes += count * sizeof(T);
     return RT_OK;
@@ -189,6 +191,8 @@ void parallel_for(size_t n, F fn) {
     }
     for (auto &t : pool) t.join();
 }
+
+bool is_special_flags(uint32_t prim_flags) { return (prim_flags & PRIM_EMISSIVE) || !(prim_flags & PRIM_ILLUM_TERMINAL); }
 
 uint32_t morton2(uint32_t x, uint32_t y) {
     auto spread = [](uint32_t v) {
@@ -273,6 +277,10 @@ struct RenderCtx {
     rt_render_params plan_key{};
     WorkList plan_wl{};
     bool plan_scattered = false;  // plan_wl is in scattered order (a call of several batches)
+    // node slots per camera ray assumed before anything was measured: 16 for a scene of Phong surfaces (a colour node has
+    // at most one reflection child; of its GI rays one in ten gets a node: scene.json 8.2, mesh.json 3), 96 where physical
+    // materials are common (32 reflection children at level 0, 4 each at level 1: physical.json 70)
+    uint32_t guess_nodes_per_item = 64;
     double est_nodes_per_item = 0.0, est_jobs_per_item = 0.0, est_specials_per_item = 0.0;
     // camera rays one batch can hold, from the largest expansion seen so far (0: nothing seen yet)
     double fit_items() const {
@@ -295,7 +303,9 @@ struct rt_scene {
     bool bvh_on_device = false;  // the tree was built by rt_bvh_device.hip.h
     GiTune gi_tune;  // rt_tune.h
 
-    uint64_t pool_bytes = 24ull << 30;  // one batch for 800x800x4spp scene.json (108 M nodes); 8 % of the 288 GB
+    uint64_t pool_bytes = 24ull << 30;  // upper limit of the wavefront pools; 8 % of the 288 GB
+    bool pool_explicit = false;         // set by rt_scene_set_pool_bytes: take it as it is
+    uint32_t guess_nodes_per_item = 64; // RenderCtx::guess_nodes_per_item of this scene
     void *pool_mem = nullptr;
     uint64_t pool_mem_bytes = 0;
     RenderCtx ctx;
@@ -394,14 +404,21 @@ int ensure_pools(rt_scene *s) {
         s->pool_mem = nullptr;
         s->pool_mem_bytes = 0;
     }
-    // the default budget is a sixth of an idle MI355X; never ask for more than 80 % of what is free right now
+    // Sized from the scene: what a whole frame needs at 64 node slots per camera ray (scene.json uses 8, physical.json 70:
+    // a frame that needs more takes several batches), at least 256 MiB, at most the budget (default 24 GiB) -- a 200x200
+    // frame asks for 2 GiB, not 24.  A budget the caller set is taken as it is.  Never more than 80 % of what is free.
     uint64_t want = s->pool_bytes;
+    if (!s->pool_explicit) {
+        const uint64_t frame_items = static_cast<uint64_t>(s->dev.opts.width) * s->dev.opts.height * s->dev.opts.samples_per_pixel;
+        want = std::min<uint64_t>(want, std::max<uint64_t>(256ull << 20, frame_items * 64u * POOL_BYTES_PER_NODE));
+    }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 10 * 8) want = free_b / 10 * 8;
     if (want < (1ull << 20)) return fail(RT_ERR_NOMEM, "less than 1 MiB of device memory free for the wavefront pools");
     HIP_TRY(hipMalloc(&s->pool_mem, want));
     s->pool_mem_bytes = s->pool_bytes;  // the budget this allocation answers (may be clamped)
     if (int rc = carve_pools(s->pool_mem, want, &ctx.np, &ctx.gp)) return rc;
+    ctx.guess_nodes_per_item = s->guess_nodes_per_item;
     if (!ctx.d_ctr) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx.d_ctr), MAX_SHARDS * sizeof(Counters)));
     if (!ctx.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx.h_ctr), MAX_SHARDS * sizeof(Counters)));
     ctx.forget_estimates();
@@ -469,8 +486,13 @@ int plan_tiles(const rt_render_options &o, const rt_render_params *prm, std::vec
 }
 
 // Camera rays of the first batch of a call (later batches are sized from the expansion the earlier ones showed).
+// Nothing seen yet (a scene's first call): a guess from scene facts (RenderCtx::guess_nodes_per_item).  A guess that
+// overflows costs a re-run of the batch (physical.json's first frame took 64 ms instead of 49 when every scene started
+// from 64 slots per camera ray), one that is too cautious costs batches (scene.json's first frame took two: +9 %), and a
+// small pilot batch to measure the expansion costs more than either on scenes with deep trees (a 1/32 batch of
+// mesh_test.json: 3.5 ms of launch tails in a 10 ms frame).
 uint64_t first_batch_items(const RenderCtx &c, uint64_t total_items, uint32_t ns) {
-    uint64_t batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, c.np.capacity / 64));
+    uint64_t batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, c.np.capacity / c.guess_nodes_per_item));
     const double fit = c.fit_items();
     if (fit > 0.0) batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, static_cast<uint64_t>(0.7 * fit)));
     return batch;
@@ -934,8 +956,10 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     // only if max_reflected_rays > 0 or opacity < 1: otherwise an illumination ray's result is the emissive colour
     std::vector<uint32_t> prim_flags(d->n_prims);
     uint32_t n_special[2] = {0, 0};  // [0] emissive or casting child rays, [1] emissive (what is special on the last traced level)
+    uint32_t n_physical = 0;
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const rt_material &m = d->materials[shade[i].material];
+        n_physical += m.kind == RT_MAT_PHYSICAL ? 1u : 0u;
         const bool terminal = m.kind == RT_MAT_PHONG ? !(m.reflectivity > 0.0) : (o.max_reflected_rays == 0 && !(m.opacity < 1.0));
         const bool emissive = m.emissive[0] != 0.0 || m.emissive[1] != 0.0 || m.emissive[2] != 0.0;
         prim_flags[i] = (terminal ? PRIM_ILLUM_TERMINAL : 0u) | (emissive ? PRIM_EMISSIVE : 0u);
@@ -948,8 +972,35 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     BvhBuildResult bvh_s[2];
     std::vector<LeafPrim> leaf_s[2];
     bool set_ok[2] = {static_cast<uint64_t>(n_special[0]) * 8u <= d->n_prims, static_cast<uint64_t>(n_special[1]) * 8u <= d->n_prims};
-    // the starting configuration (what small renders stay with) and the switches the tuner may flip
-    sc->gi_tune.configure(set_ok, n_bounded >= 32768, std::getenv("MI355RT_GI_TWO_PHASE"), std::getenv("MI355RT_GI_WAVES"));
+    // the starting configuration (what a one-frame process and small renders run with: a rule from scene facts, rt_tune.h)
+    // and the switches the tuner may flip
+    //   two-phase queries pay when (a) the second phase, an any-hit search within max_occlusion_distance D, is much
+    //   shorter than a closest-hit query: D <= extent / 4 (D = 1 in scenes of extent 5 ... 550: GI rays 0.20 -> 0.095 ms per
+    //   million on mesh.json), and (b) the first phase, the closest SPECIAL hit, is cheap and seldom finds anything: the
+    //   special primitives' boxes together are at most half the root box's area (scene.json: the room, a cube around
+    //   everything, is special -- every ray has a special hit far away, the first phase comes on top: +6 %);
+    //   the last level's illumination nodes apart (k_trace_illum_last) where the tree is deep enough for its any-hit
+    //   form to matter (2,048 bounded primitives: mesh.json +8 %, mesh_test.json +15 %; within +-3 % elsewhere).
+    uint32_t start = 0;
+    if (n_bounded) {
+        auto area = [](const Aabb &b) {
+            const double dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+            return 2.0 * (dx * dy + dy * dz + dz * dx);
+        };
+        double extent = 0.0, special_area[2] = {0.0, 0.0};
+        for (int k = 0; k < 3; ++k) extent = std::fmax(extent, bvh.root_box.mx[k] - bvh.root_box.mn[k]);
+        for (size_t b = 0; b < n_bounded; ++b) {
+            const uint32_t f = prim_flags[bounded_ids[b]];
+            if (is_special_flags(f)) special_area[0] += area(cull_boxes[b]);
+            if (f & PRIM_EMISSIVE) special_area[1] += area(cull_boxes[b]);
+        }
+        const double root_area = area(bvh.root_box);
+        const bool short_occlusion = o.max_occlusion_distance * 4.0 <= extent;
+        if (short_occlusion && special_area[0] <= 0.5 * root_area) start |= GiTune::GI_INNER;
+        if (short_occlusion && special_area[1] <= 0.5 * root_area) start |= GiTune::GI_LAST;
+        if ((start & GiTune::GI_LAST) && n_bounded >= 2048) start |= GiTune::ILLUM_LAST;
+    }
+    sc->gi_tune.configure(set_ok, start, std::getenv("MI355RT_GI_TWO_PHASE"), std::getenv("MI355RT_GI_WAVES"));
     for (int q = 0; q < 2; ++q) {
         if (!set_ok[q] || n_special[q] == 0) continue;
         std::vector<uint32_t> sub;  // indices into bounded_ids
@@ -967,6 +1018,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         leaf_s[q].resize(bvh_s[q].order.size());
         for (size_t j = 0; j < leaf_s[q].size(); ++j) leaf_s[q][j] = leaf_record(sub[bvh_s[q].order[j]]);
     }
+    sc->guess_nodes_per_item = (static_cast<uint64_t>(n_physical) * 4u >= d->n_prims && o.max_reflected_rays > 1) ? 96u : 16u;
     lap("special primitives");
     sc->n_nodes = n_built_nodes;
     sc->n_leaves = bvh.n_leaves;
@@ -1081,6 +1133,7 @@ int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes) {
     if (!scene) return fail(RT_ERR_INVALID, "null scene");
     if (bytes < (1ull << 20)) return fail(RT_ERR_INVALID, "pool budget below 1 MiB");
     scene->pool_bytes = bytes;
+    scene->pool_explicit = true;
     return RT_OK;
 }
 
@@ -1147,11 +1200,15 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     const uint32_t gi_cfg = s->gi_tune.pick();
     const bool gi_waves3 = (gi_cfg & GiTune::WAVES3) != 0;
     s->dev.gi_two_phase = gi_cfg & 7u;
+    // a call can only be used by the tuner if it traces at least TUNE_MIN_RAYS GI rays: one that cannot (fewer camera
+    // rays than that many hemisphere rays of level 0 need) is not timed -- no events are created for it
+    constexpr uint64_t TUNE_MIN_RAYS = 1000000u;
+    const bool gi_tuning = s->gi_tune.exploring() && &ctx == &s->ctx;
+    const bool gi_can_qualify = plan.total_items * gi_rays_host(s->dev.opts, 0) >= TUNE_MIN_RAYS && !count_work;
     EventTimer gi_timer;
-    gi_timer.enabled = s->gi_tune.exploring() && &ctx == &s->ctx && !stats;  // with stats the main timer has the figure
+    gi_timer.enabled = gi_tuning && gi_can_qualify && !stats;  // with stats the main timer has the figure
     gi_timer.stream = stream;
     gi_timer.chaining = false;
-    const bool gi_tuning = s->gi_tune.exploring() && &ctx == &s->ctx;
     double gi_ms = 0.0;
     uint64_t gi_rays_call = 0, tune_rays_call = 0;
     EventPair call_ev;
@@ -1215,7 +1272,11 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
                 if (level + 1 < max_depth && gi_rays_host(s->dev.opts, level) <= GI_MAX_INPLACE) {  // the GI rays of this level's hits, in place
                     timer.begin(CLS_GI);
                     gi_timer.begin(CLS_GI);
-                    auto *kern = count_work ? (gi_waves3 ? k_trace_gi<true, 3> : k_trace_gi<true, 4>) : (gi_waves3 ? k_trace_gi<false, 3> : k_trace_gi<false, 4>);
+                    // the level's form of query is compiled in: a build with one traversal fits its register budget
+                    const uint32_t set = level + 2 < max_depth ? 0u : 1u;  // the GI rays' own children are traced (set 0) or cut off (set 1)
+                    const bool tp = ((s->dev.gi_two_phase >> set) & 1u) && s->dev.special[set].ok;
+                    auto *kern = tp ? (count_work ? (gi_waves3 ? k_trace_gi<true, 3, true> : k_trace_gi<true, 4, true>) : (gi_waves3 ? k_trace_gi<false, 3, true> : k_trace_gi<false, 4, true>))
+                                    : (count_work ? (gi_waves3 ? k_trace_gi<true, 3, false> : k_trace_gi<true, 4, false>) : (gi_waves3 ? k_trace_gi<false, 3, false> : k_trace_gi<false, 4, false>));
                     hipLaunchKernelGGL(kern, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, wl, np, gp, d_ctr, sh, level + 1, stack_entries(s));
                     timer.end();
                     gi_timer.end();
@@ -1341,7 +1402,8 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         ctx.est_jobs_per_item = call_max[1];
         ctx.est_specials_per_item = call_max[2];
     }
-    if (gi_tuning && !count_work && st.retries == 0 && gi_rays_call >= 1000000u && gi_ms > 0.0) {
+    if (gi_tuning && !(gi_can_qualify && st.retries == 0 && gi_rays_call >= TUNE_MIN_RAYS && gi_ms > 0.0)) s->gi_tune.skip();
+    if (gi_tuning && gi_can_qualify && st.retries == 0 && gi_rays_call >= TUNE_MIN_RAYS && gi_ms > 0.0) {
         GiTune &t = s->gi_tune;
         t.record(gi_cfg, gi_ms / (1e-6 * static_cast<double>(tune_rays_call)));
         if (!t.exploring() && std::getenv("MI355RT_TIMING")) {
@@ -1429,6 +1491,7 @@ int rt_render_device_noalloc(rt_scene *s, const rt_render_params *params, double
         // the scratch is shared by every scene on this device: its plan cache and expansion estimates belong to the last caller
         f.ctx.plan_valid = false;
         f.ctx.forget_estimates();
+        f.ctx.guess_nodes_per_item = s->guess_nodes_per_item;
         return render_impl(s, f.ctx, params, d_rgb_accum, nullptr, nullptr, ray_count, nullptr, static_cast<hipStream_t>(stream_v));
     });
 }

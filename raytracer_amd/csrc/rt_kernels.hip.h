@@ -507,17 +507,18 @@ struct ObjRayCache {
     RayD r;
 };
 
-// The whole 128-byte record is requested at once (eight 16-byte loads of one cache
-// line) before anything is decided: asked for piecemeal -- meta, then the geometry
-// the type needs, then the box of a hit, then the id of an accepted hit -- a leaf
-// costs up to four dependent trips to the vector cache, and those waits, not the
-// arithmetic, are what the traversal kernels spend their time on.
+// The record's geometry half (80 bytes: five 16-byte loads of one cache line, meta and id included) is requested at
+// once before anything is decided: asked for piecemeal -- meta, then the geometry the type needs, then the id of an
+// accepted hit -- a leaf costs dependent trips to the vector cache.  The primitive's own box (the line's first 48
+// bytes) is fetched only for primitive hits (3-4 % of the tests on meshes) and hits L1: holding it from the start cost
+// 12 VGPRs at the kernels' register peak -- spills in every traversal kernel at 128 VGPRs (k_trace_gi 8.6 -> 7.7 ms
+// on scene.json without them).
 template <bool SHADOW>
 __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPrim *__restrict__ lp, const RayD &ray,
                                                ObjRayCache &cache, double max_distance, HitRec *h, uint32_t *prim_id,
                                                uint32_t *prim_type = nullptr, uint32_t *exact_box = nullptr) {
     const double2 *q = reinterpret_cast<const double2 *>(lp);
-    const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+    const double2 q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
     const uint4 tail = reinterpret_cast<const uint4 *>(lp)[7];  // geom[8] | prim_id | meta
     const uint32_t meta = tail.w;
     *prim_id = tail.z;
@@ -534,6 +535,7 @@ __device__ __forceinline__ bool test_leaf_prim(const SceneDev &sc, const LeafPri
                             __hiloint2double(static_cast<int>(tail.y), static_cast<int>(tail.x))};
     double t_probe;
     if (!hit_bounded<SHADOW>(geom, type, side, cache.r, max_distance, h, &t_probe)) return false;
+    const double2 q0 = q[0], q1 = q[1], q2 = q[2];  // the primitive's own box: the same cache line again, for primitive hits only
     const double center[3] = {q0.x, q0.y, q1.x}, half[3] = {q1.y, q2.x, q2.y};
     if (prim_box_surely_passes(center, half, ray, t_probe, SHADOW, max_distance)) return true;
     if (exact_box) *exact_box = 1u;
@@ -845,7 +847,20 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
 // compiler keeps the sampling routine's f64 constants in registers across the traversal) or 3 (168 VGPRs, 5 spilled).
 // Three are faster where the tree sits in LDS / L2 (scene.json -6 %, cornell_box -12 %), four where its misses need
 // hiding (the 1M-triangle scene +8 % with three); rt_api.hip times both on the scene's first frames.
-template <bool COUNT, int WAVES>
+// A GI ray of a job: drawn about the job's normal (the same Philox key and sampler as a stored child would get), :115.
+// A call, not inlined: the sampler's constants and temporaries then end at the call's return instead of staying live
+// across the traversal that follows (the kernel is cut for 128 VGPRs: 43 of them spilled with the draw inlined, 10
+// now), and the four-wave build became the faster one on every scene.
+__device__ __noinline__ RayD gi_draw(const GiJob *job, uint64_t seed, uint32_t slot) {
+    const d3 P = mk3(job->P[0], job->P[1], job->P[2]), n = mk3(job->n[0], job->n[1], job->n[2]);
+    double u1, u2;
+    rng_pair(seed, job->pixel, job_sample(job->sample_gi), path_child(job->path, SLOT_GI + slot), &u1, &u2);
+    RayD ray;
+    ray.d = sample_direction(SAMPLE_HEMISPHERE, n, 0.0, u1, u2);
+    ray.o = P + ray.d * BIAS;  // :115
+    return ray;
+}
+template <bool COUNT, int WAVES, bool TWO_PHASE>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList wl, NodePool np, GiPool gp, Counters *ctrs, Shards shards, uint32_t level,
                                                    uint32_t stack_entries) {
     extern __shared__ __align__(16) uint32_t stack_lds[];
@@ -883,7 +898,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
     const uint32_t lane = threadIdx.x & 63u;
     const bool next_real = level + 1u < sc.opts.max_depth;  // children of this level's hits are traced (else they return zero, :495-497)
     const uint32_t set = next_real ? 0u : 1u;                // which primitives are special on this level
-    const bool two_phase = ((sc.gi_two_phase >> set) & 1u) && sc.special[set].ok;
+    constexpr bool two_phase = TWO_PHASE;  // the host's choice for this level: (sc.gi_two_phase >> set) & 1 and sc.special[set].ok
     unsigned long long n_nodes = 0, n_prims = 0;
     uint32_t wave_rays = 0, wave_nodes = 0;  // wave-uniform
     for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
@@ -899,12 +914,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
         double hit_t = 0.0, hit_bu = 0.0, hit_bv = 0.0;
         RayD ray;
         if (valid) {
-            const GiJob &job = gp.jobs[job_index];
-            const d3 P = mk3(job.P[0], job.P[1], job.P[2]), n = mk3(job.n[0], job.n[1], job.n[2]);
-            double u1, u2;
-            rng_pair(wl.seed, job.pixel, job_sample(job.sample_gi), path_child(job.path, SLOT_GI + slot), &u1, &u2);
-            ray.d = sample_direction(SAMPLE_HEMISPHERE, n, 0.0, u1, u2);
-            ray.o = P + ray.d * BIAS;  // :115
+            ray = gi_draw(gp.jobs + job_index, wl.seed, slot);
             if (two_phase) {  // closest special hit, then: does anything precede it / lie within the occlusion distance?
                 const CullRay cr = make_cull_ray(ray, sc.scene_scale, sc.q_origin, sc.q_scale);
                 uint32_t s_key = 0;

@@ -74,17 +74,20 @@ def test_every_variant_the_library_may_pick_gives_the_same_frame():
     assert len(seen) == 4
     for acc, n in frames[1:]:
         assert n == frames[0][1] and np.array_equal(acc, frames[0][0])
-    # unpinned: an untimed call, one with the starting configuration, then one flip per switch (cornell_box: both special sets
-    # are small, so all four switches are open), then one configuration stays
+    # unpinned: an untimed call, two with the starting configuration (cornell_box: max_occlusion_distance 1 in a scene of
+    # extent 550 -> two-phase GI queries, four waves), then two per switch (both special sets are small, so all four
+    # switches are open), then one configuration stays -- and it is one of those that were tried
     g = device.DeviceScene(s.desc, pool_bytes=2 << 30)
     picks = []
-    for _ in range(9):
+    for _ in range(14):
         acc, _, n, st = g.render(want_rgba=False, want_stats=True)
         assert n == frames[0][1] and np.array_equal(acc, frames[0][0])
         picks.append((st.gi_two_phase, st.gi_waves))
     assert st.gi_rays >= 1000000, "the frame is too small to settle anything"
-    assert picks[0] == picks[1] == (7, 3), picks
-    assert len(set(picks[1:6])) == 5 and len(set(picks[6:])) == 1, picks
+    assert picks[0] == picks[1] == picks[2] == (3, 4), picks
+    trials = picks[1:11]
+    assert all(trials[i] == trials[i + 1] for i in range(0, 10, 2)) and len(set(trials)) == 5, picks
+    assert len(set(picks[11:])) == 1 and picks[11] in trials, picks
 
 
 @pytest.mark.parametrize("seed", range(32))

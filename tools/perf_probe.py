@@ -11,7 +11,7 @@ pools = [float(x) for x in sys.argv[2:]] or [8.0]
 s = host.LoadedScene.from_file(f"scenes/{name}.json")
 for gib in pools:
     g = device.DeviceScene(s.desc, pool_bytes=int(gib * (1 << 30)))
-    for it in range(9):
+    for it in range(14):
         t0 = time.perf_counter()
         _, _, n, st = g.render(want_rgba=False, want_stats=True)
         dt = time.perf_counter() - t0

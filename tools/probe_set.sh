@@ -7,7 +7,7 @@ mkdir -p $out
 for sc in $scenes; do
   MI355RT_TIMING=1 timeout -k 10 200 python tools/perf_probe.py $sc 24 > $out/probe_$sc.txt 2>&1 || exit 1
   grep "closest-hit kernels" $out/probe_$sc.txt
-  tail -n 3 $out/probe_$sc.txt | head -n 2
+  tail -n 3 $out/probe_$sc.txt | head -n 2 | cut -c1-230
 done
 timeout -k 10 200 python tools/perf_shard.py 8 8 > $out/shard.txt 2>&1 || exit 1
 tail -n 3 $out/shard.txt
