@@ -1000,7 +1000,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         if (short_occlusion && special_area[1] <= 0.5 * root_area) start |= GiTune::GI_LAST;
         if ((start & GiTune::GI_LAST) && n_bounded >= 2048) start |= GiTune::ILLUM_LAST;
     }
-    sc->gi_tune.configure(set_ok, start, std::getenv("MI355RT_GI_TWO_PHASE"), std::getenv("MI355RT_GI_WAVES"));
+    sc->gi_tune.configure(set_ok, start, std::getenv("MI355RT_GI_TWO_PHASE"), std::getenv("MI355RT_GI_WAVES"), std::getenv("MI355RT_GI_CFG"));
     for (int q = 0; q < 2; ++q) {
         if (!set_ok[q] || n_special[q] == 0) continue;
         std::vector<uint32_t> sub;  // indices into bounded_ids
@@ -1102,6 +1102,10 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     if ((rc = upload(st, d->tri_uv, 6ull * d->n_tris, &dev.tri_uv, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, d->materials, static_cast<size_t>(d->n_materials), &dev.materials, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, lights, &dev.lights, sc->allocs, bytes))) return rc;
+    std::vector<DLight> point_lights;
+    for (const DLight &l : lights)
+        if (l.kind == RT_LIGHT_POINT) point_lights.push_back(l);
+    if ((rc = upload(st, point_lights, &dev.point_lights, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, texs, &dev.textures, sc->allocs, bytes))) return rc;
     if ((rc = upload(st, texels, &dev.texels, sc->allocs, bytes))) return rc;
     lap("upload");

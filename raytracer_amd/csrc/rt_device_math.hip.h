@@ -409,8 +409,10 @@ __device__ __forceinline__ bool hit_bounded(const double *__restrict__ g, uint32
 //   * every slab is widened by P = 2^-20 (|o|_inf + scene scale) on each side,
 //     which absorbs the f32 rounding of the origin-side constants (<= 2^-23 |o|)
 //     and the rounding of the primitives' reference-order AABB arithmetic in f64;
-//   * inv = 1/d and the fma carry a relative error <= 2^-23: entry distances are
-//     lowered and exit distances raised by 2^-21 relative;
+//   * inv = 1/d is taken in f32 (v_rcp_f32 of the direction rounded to f32: relative
+//     error <= 1.5 * 2^-23, the same factor on both constants of an axis, so it scales
+//     that axis' distances) and the fma adds 2^-24: entry distances are lowered and
+//     exit distances raised by 2^-21 relative, more than twice what is needed;
 //   * |1/d| is clamped to 1e25, so a ray parallel to a slab (d = +-0) gets
 //     entry/exit distances of magnitude >= 1e25 * P with the right signs, no
 //     inf - inf; comparisons are written so that a NaN (NaN ray) keeps the node.
@@ -419,29 +421,31 @@ struct CullRay {
     float x1, x2, y1, y2, z1, z2;  // (q_origin - (o + P)) / d and (q_origin - (o - P)) / d per axis
 };
 
-__device__ __forceinline__ double cull_inv(double d) {
-    const double inv = 1.0 / d;  // +-inf for +-0
-    const double lim = 1e25;     // |t| beyond 1e25 * P is no hit distance of a bounded scene
-    return fabs(inv) < lim ? inv : copysign(lim, inv);  // NaN direction -> +-1e25, still finite
+__device__ __forceinline__ float cull_inv(double d) {
+    const float inv = __builtin_amdgcn_rcpf(static_cast<float>(d));  // +-inf for +-0 (and for what rounds or flushes to it)
+    const float lim = 1e25f;     // |t| beyond 1e25 * P is no hit distance of a bounded scene
+    return fabsf(inv) < lim ? inv : copysignf(lim, inv);  // NaN direction -> +-1e25, still finite
 }
 
 // Slab distances are evaluated as fma(q, a, c) with q the 16-bit box coordinate:
-// (q_origin + q q_scale - (o +- P)) / d.  The f32 rounding of a and c displaces
-// the box by <= 2^-23 (scene scale + |o|), far inside P.
+// (q_origin + q q_scale - (o +- P)) / d.  The differences q_origin - (o +- P) are
+// taken in f64 (o is near the box: cancellation) and rounded to f32, the products
+// with 1/d are f32: each rounding displaces the box by <= 2^-24 (scene scale + |o|
+// + P) or 2^-24 of its extent -- P / 4 in all, inside P.
 __device__ __forceinline__ CullRay make_cull_ray(const RayD &r, double scene_scale, const float *q_origin, const float *q_scale) {
     const double m = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
     const double P = 0x1.0p-20 * (m + scene_scale);
-    const double ix = cull_inv(r.d.x), iy = cull_inv(r.d.y), iz = cull_inv(r.d.z);
+    const float ix = cull_inv(r.d.x), iy = cull_inv(r.d.y), iz = cull_inv(r.d.z);
     CullRay c;
-    c.ax = static_cast<float>(static_cast<double>(q_scale[0]) * ix);
-    c.ay = static_cast<float>(static_cast<double>(q_scale[1]) * iy);
-    c.az = static_cast<float>(static_cast<double>(q_scale[2]) * iz);
-    c.x1 = static_cast<float>((static_cast<double>(q_origin[0]) - (r.o.x + P)) * ix);
-    c.x2 = static_cast<float>((static_cast<double>(q_origin[0]) - (r.o.x - P)) * ix);
-    c.y1 = static_cast<float>((static_cast<double>(q_origin[1]) - (r.o.y + P)) * iy);
-    c.y2 = static_cast<float>((static_cast<double>(q_origin[1]) - (r.o.y - P)) * iy);
-    c.z1 = static_cast<float>((static_cast<double>(q_origin[2]) - (r.o.z + P)) * iz);
-    c.z2 = static_cast<float>((static_cast<double>(q_origin[2]) - (r.o.z - P)) * iz);
+    c.ax = q_scale[0] * ix;
+    c.ay = q_scale[1] * iy;
+    c.az = q_scale[2] * iz;
+    c.x1 = static_cast<float>(static_cast<double>(q_origin[0]) - (r.o.x + P)) * ix;
+    c.x2 = static_cast<float>(static_cast<double>(q_origin[0]) - (r.o.x - P)) * ix;
+    c.y1 = static_cast<float>(static_cast<double>(q_origin[1]) - (r.o.y + P)) * iy;
+    c.y2 = static_cast<float>(static_cast<double>(q_origin[1]) - (r.o.y - P)) * iy;
+    c.z1 = static_cast<float>(static_cast<double>(q_origin[2]) - (r.o.z + P)) * iz;
+    c.z2 = static_cast<float>(static_cast<double>(q_origin[2]) - (r.o.z - P)) * iz;
     return c;
 }
 

@@ -131,6 +131,7 @@ struct SceneDev {
     const double *tri_uv;     // [n_tris*6]
     const rt_material *materials;
     const DLight *lights;
+    const DLight *point_lights;  // the point lights among them, in order (shadow-ray light index -> light)
     const DTexture *textures;
     const uint8_t *texels;
     uint32_t n_lights;

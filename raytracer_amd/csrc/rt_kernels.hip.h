@@ -1133,13 +1133,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
             uint32_t mm = pm;  // slot-th set bit of the job's light mask -> index among the point lights
             for (uint32_t k = 0; k < slot; ++k) mm &= mm - 1u;
             const uint32_t want = static_cast<uint32_t>(__ffs(mm)) - 1u;
-            uint32_t li = 0, seen = 0;
-            for (; li < sc.n_lights; ++li) {
-                if (sc.lights[li].kind != RT_LIGHT_POINT) continue;
-                if (seen == want) break;
-                seen++;
-            }
-            const DLight &l = sc.lights[li];
+            const DLight &l = sc.point_lights[want];
             const double *Pp = gp.jobs[first_job + p].P;
             RayD ray;
             ray.o = mk3(l.position[0], l.position[1], l.position[2]);
@@ -1264,18 +1258,28 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
                 gi_job = 0x80000000u;
                 nG = 0;
             }
-            if (cast_shadows) {
-                uint32_t bit = 0;
-                for (uint32_t li = 0; li < sc.n_lights; ++li) {
-                    const DLight &l = sc.lights[li];
-                    if (l.kind != RT_LIGHT_POINT) continue;
+            if (cast_shadows) {  // the lights on whose side the surface lies: n . l > 0 with l = normalize(L - P), :216-221 / :428-433
+                for (uint32_t bit = 0; bit < sc.n_point_lights; ++bit) {
+                    const DLight &l = sc.point_lights[bit];
                     d3 ld = mk3(l.position[0], l.position[1], l.position[2]) - s.P;
-                    ld = unit3(ld);
-                    if (dot3(s.n, ld) > 0.0) {
+                    // The sign of n . l is the sign of n . (L - P) unless that is within rounding of zero: the
+                    // reference's value differs from (n . (L - P)) / |L - P| by a few 1e-16 |n|, this product from the
+                    // exact one by a few 1e-16 B with B = |n|_1 |L - P|_1 >= |n| |L - P|.  Beyond 1e-10 B the sign is
+                    // certain and the square root and three divisions of the normalisation are not needed; inside
+                    // (and for NaN or overflow: the comparison is false) the reference's own arithmetic decides.
+                    const double s_raw = dot3(s.n, ld);
+                    const double bnd = 1e-10 * ((fabs(s.n.x) + fabs(s.n.y) + fabs(s.n.z)) * (fabs(ld.x) + fabs(ld.y) + fabs(ld.z)));
+                    bool lit;
+                    if (fabs(s_raw) > bnd) {
+                        lit = s_raw > 0.0;
+                    } else {
+                        ld = unit3(ld);
+                        lit = dot3(s.n, ld) > 0.0;
+                    }
+                    if (lit) {
                         mask |= 1u << bit;
                         nS++;
                     }
-                    bit++;
                 }
             }
             if (gi_job || nS) {  // the colour node's job: its shadow rays and (gi_job) its GI rays

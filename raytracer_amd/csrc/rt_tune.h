@@ -42,12 +42,22 @@ struct GiTune {
     // what the sets allow; rt_api.hip scene_create_impl derives it), so that a process that renders one frame (the
     // reference's use, main.rs:58-77) already runs what the walk would settle on; the four-wave build (faster on all eight
     // published scenes since the traversal stopped spilling).
-    void configure(bool set_ok[2], uint32_t start, const char *pin_two_phase, const char *pin_waves) {
+    // pin_cfg: MI355RT_GI_CFG = the whole configuration as a number (GI_INNER 1 | GI_LAST 2 | ILLUM_LAST 4 | WAVES3 8), for
+    // profiler runs that must describe one variant: nothing is explored, the sets the bits need are forced usable.
+    void configure(bool set_ok[2], uint32_t start, const char *pin_two_phase, const char *pin_waves, const char *pin_cfg = nullptr) {
         cfg = 0;
         n_dims = 0;
         step = -1;
         rep = skipped = 0;
         acc = 0.0;
+        if (pin_cfg) {
+            uint32_t v = 0;
+            for (const char *c = pin_cfg; *c >= '0' && *c <= '9'; ++c) v = v * 10u + static_cast<uint32_t>(*c - '0');
+            cfg = v & 15u;
+            if (cfg & GI_INNER) set_ok[0] = true;
+            if (cfg & (GI_LAST | ILLUM_LAST)) set_ok[1] = true;
+            return;
+        }
         if (pin_two_phase) {
             set_ok[0] = set_ok[1] = std::strcmp(pin_two_phase, "0") != 0;
             if (set_ok[0]) cfg = GI_INNER | GI_LAST | ILLUM_LAST;

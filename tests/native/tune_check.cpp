@@ -114,6 +114,10 @@ int main() {
         bool ok3[2] = {true, false};
         v.configure(ok3, 3u, nullptr, "3");
         CHECK(v.n_dims == 1 && v.cfg == (1u | 8u) && v.dims[0] == GiTune::GI_INNER);
+        GiTune w;  // the whole configuration pinned (profiler runs)
+        bool ok4[2] = {false, false};
+        w.configure(ok4, 7u, nullptr, nullptr, "10");
+        CHECK(w.n_dims == 0 && !w.exploring() && w.pick() == 10u && !ok4[0] && ok4[1]);
     }
     std::printf("OK\n");
     return 0;
