@@ -33,7 +33,7 @@
 //   ORC_MODE_KD        the reference's SAH kd-tree and its exact traversal order
 //                      (tie-breaks, max_distance threading) -- the CPU baseline.
 //   ORC_MODE_CANONICAL traversal-order independent statement of the same hit
-//                      predicate: closest = min over primitives of (t, bounded?, id),
+//                      predicate: closest = min over primitives of (t, bounded?, -id),
 //                      shadow = OR over primitives; every bounded primitive keeps
 //                      its own world-AABB slab test (bounds.rs:172-181).  This is
 //                      the bit-exact target for the GPU (DESIGN.md "canonical hit").
@@ -797,7 +797,7 @@ struct Tracer {
         if (best.distance < h.distance) return false;
         if (h.distance == best.distance) {
             if (h_bounded != best_bounded) return !h_bounded;
-            return h.prim->id < best.prim->id;
+            return h.prim->id > best.prim->id;  // the later primitive first: what MODE_KD gives on cornell_box's coplanar light / ceiling
         }
         return false;  // NaN: keep the earlier one
     }

@@ -614,11 +614,21 @@ __device__ __forceinline__ uint32_t descend(const TreeView &tv, const CullRay &c
     return cur;
 }
 
+// Order of two hits at EXACTLY the same distance (the smaller key comes first).  The reference takes the first minimum
+// in iteration order (bounds.rs:303-307, :344-353, :359-362): unbounded objects in scene order, then the tree's hit --
+// so an unbounded object precedes a bounded one and the earlier of two unbounded ones wins, which the key keeps.  Among
+// bounded primitives its order is the kd-tree's traversal order, which no other accelerator has; the key puts the
+// primitive with the HIGHER id first: on the one shipped scene with exact ties (cornell_box: the light's two triangles,
+// ids 26 / 27, coplanar with the ceiling's, 20 / 21 -- quirk Q17) that is what the reference's own tree and order give on
+// all 2,386 tied pixel centres of the 800x800 frame (tests/test_gpu_parity.py, the CPU restatement of its tree; with the lower id first they all differed and the
+// frame's radiance was 5e-2 rms off, the light's emission lost to the ceiling wherever a GI ray met the tie).
+__device__ __forceinline__ uint32_t tie_key_bounded(uint32_t prim_id) { return 0x80000000u | (0x7FFFFFFFu - prim_id); }
+
 // KdTreeAccelerator::raycast (bounds.rs:302-308) for one ray, in the traversal-order independent form: the unbounded
-// objects, then the BVH; minimum of (t, bounded?, primitive id).  Shared by k_trace_closest and k_trace_gi.
+// objects, then the BVH; minimum of (t, tie key).  Shared by k_trace_closest and k_trace_gi.
 // SPECIAL: only the special primitives (PRIM_* flags: emissive, or an illumination hit needs child rays) -- the planes
 // among them and the tree `tv` of the bounded ones; `key_out` then gets the rest of the winner's ordering key
-// (bit 31: bounded; low bits: plane list index / primitive id).  `shared_cr`: the ray's CullRay if the caller has it.
+// (tie_key_bounded of a bounded winner, the plane list index of an unbounded one).  `shared_cr`: the ray's CullRay if the caller has it.
 template <bool COUNT, bool SPECIAL>
 __device__ __forceinline__ void closest_hit(const SceneDev &sc, const TreeView &tv, uint32_t *stack, const RayD &ray, Counters *ctr,
                                             unsigned long long &n_nodes, unsigned long long &n_prims, uint32_t *id_out, double *t_out,
@@ -677,7 +687,7 @@ __device__ __forceinline__ void closest_hit(const SceneDev &sc, const TreeView &
                     }
                 }
                 if (leaf_hit) {
-                    bool better = best_id == RT_NO_HIT || h.t < best_t || (h.t == best_t && best_bounded && pid < best_id);
+                    bool better = best_id == RT_NO_HIT || h.t < best_t || (h.t == best_t && best_bounded && pid > best_id);
                     if (better) {
                         best_t = h.t;
                         best_id = pid;
@@ -694,12 +704,12 @@ __device__ __forceinline__ void closest_hit(const SceneDev &sc, const TreeView &
     *t_out = best_t;
     *bu_out = best_bu;
     *bv_out = best_bv;
-    if (key_out) *key_out = best_bounded ? (0x80000000u | best_id) : best_plane;
+    if (key_out) *key_out = best_bounded ? tie_key_bounded(best_id) : best_plane;
 }
 
 // The second half of a two-phase GI query (k_trace_gi): given the closest SPECIAL hit S of the ray (s_exists, s_t,
 // s_key as closest_hit<., true> returns them), decide what the closest hit over ALL primitives would be without
-// finding it: any primitive that precedes S in the order (t, bounded?, id) makes the closest hit a plain one, and of
+// finding it: any primitive that precedes S in the order (t, tie key) makes the closest hit a plain one, and of
 // a plain hit get_illumination (:492-520) uses nothing but `distance <= max_occlusion_distance` (D).  So the search
 // stops at the first preceding hit within D, and once a preceding hit beyond D is known only hits within D matter.
 // A special primitive met again here never precedes S (S is the first of them; the same record gives the same t).
@@ -719,7 +729,7 @@ __device__ __forceinline__ uint32_t any_hit_before(const SceneDev &sc, const Tre
         HitRec h;
         if (COUNT) n_prims++;
         if (!hit_plane(mk3(pl.normal[0], pl.normal[1], pl.normal[2]), (pl.meta >> 2) & 3u, false, orr, false, 0.0, &h)) continue;
-        if (s_exists && !(h.t < s_t || (h.t == s_t && p < s_key))) continue;  // an unbounded S has key = its list index; a bounded one 2^31 + id
+        if (s_exists && !(h.t < s_t || (h.t == s_t && p < s_key))) continue;  // an unbounded S has key = its list index; a bounded one tie_key_bounded(id)
         if (h.t <= D) within = true;
         if (s_exists || h.t <= D) found = true;
         if (!within) limit = D;
@@ -739,7 +749,7 @@ __device__ __forceinline__ uint32_t any_hit_before(const SceneDev &sc, const Tre
                 if (COUNT) n_prims++;
                 uint32_t pid;
                 if (!test_leaf_prim<false>(sc, tv.leaf_prims + first + k, ray, cache, 0.0, &h, &pid)) continue;
-                if (s_exists && !(h.t < s_t || (h.t == s_t && (0x80000000u | pid) < s_key))) continue;
+                if (s_exists && !(h.t < s_t || (h.t == s_t && tie_key_bounded(pid) < s_key))) continue;
                 if (h.t <= D) within = true;
                 if (s_exists || h.t <= D) found = true;
                 if (!within) limit = D;
@@ -752,7 +762,7 @@ __device__ __forceinline__ uint32_t any_hit_before(const SceneDev &sc, const Tre
 }
 
 // KdTreeAccelerator::raycast semantics, traversal-order independent form
-// (DESIGN.md "canonical hit"): minimum of (t, bounded?, primitive id).
+// (DESIGN.md "canonical hit"): minimum of (t, tie key: unbounded first, then the higher primitive id).
 //
 // FINALIZE (render path): nodes whose result needs neither child rays nor
 // shading are finished here -- misses (zero), and get_illumination hits on a

@@ -505,3 +505,47 @@ def test_work_counters(rt):
     assert n0 == n1 and np.array_equal(a0, a1)
     assert st0.nodes_visited_closest == 0 and st1.nodes_visited_closest > st1.closest_rays
     assert st1.prims_tested_closest > 0 and st1.nodes_visited_shadow > 0
+
+
+TIE_SCENES = ["test", "scene", "mesh", "refraction", "physical", "mesh_test", "occlusion", "emissive", "cornell_box"]
+
+
+@pytest.mark.parametrize("name", TIE_SCENES)
+def test_primary_ids_against_the_references_traversal_order(rt, name):
+    """The reference's closest hit is `min_by` = the FIRST minimum in kd traversal order (src/core/bounds.rs:303-307,
+    :344-353, :359-362); the kernels take the minimum of (t, tie key) whatever the traversal order (DESIGN.md
+    "canonical hit"; tie key: unbounded objects in scene order first -- the reference's own rule -- then the bounded
+    primitive with the higher id).  The two can differ only where two primitives are hit at EXACTLY the same distance.
+    At the full 800x800 the GPU's primary ids are held against the oracle's MODE_KD -- the restatement of the
+    reference's own tree and order -- on every shipped scene: no difference anywhere, cornell_box included, whose light
+    is coplanar with its ceiling (quirk Q17, scenes/models/cornell_box/light.obj / ceiling.obj, y = 548.8: 2,386 pixel
+    centres of the frame hit both at the same distance, and the reference's order gives the light on all of them)."""
+    device, ob, _ = rt
+    s = load_scene(name)
+    assert (s.opts.width, s.opts.height) == (800, 800)
+    gpu, cpu = device.DeviceScene(s.desc), ob.OracleScene(s.desc)
+    ids_g, t_g, _ = gpu.query_primary()
+    ids_k, t_k, _ = cpu.query_primary(ob.MODE_KD)
+    n = int((ids_g != ids_k).sum())
+    print(f"{name}: {n} of {ids_g.size} primary ids differ from the reference's traversal order (MODE_KD)")
+    assert n == 0
+    hit = ids_k != NO_HIT
+    assert np.array_equal(t_g[hit], t_k[hit])
+
+
+def test_cornell_box_ties_beyond_the_camera_rays(rt):
+    """Rays other than camera rays meet cornell_box's coplanar light / ceiling too (a GI ray that ends on the light
+    gathers its emission, one that ends on the ceiling nothing), and for them the reference's winner follows the kd
+    traversal order of THAT ray.  The frame against the oracle's MODE_KD: inside the radiance bar; the pixels that
+    differ at all are printed -- that remainder is PARITY UNPINNED (no reference render of cornell_box exists, and
+    which of two coplanar primitives a tie goes to is decided by last-ulp rounding on the reference's own hardware)."""
+    device, ob, _ = rt
+    s = load_scene("cornell_box", size=200, spp=4)
+    gpu, cpu = device.DeviceScene(s.desc), ob.OracleScene(s.desc)
+    acc_g, _, n_g, _ = gpu.render(want_rgba=False)
+    acc_k, _, n_k = cpu.render(mode=ob.MODE_KD, threads=16, want_rgba=False)
+    differ = int((np.abs(acc_g - acc_k).max(axis=2) > 1e-9).sum())
+    rmse = radiance_rmse(acc_g, acc_k, 4)
+    print(f"cornell_box 200x200x4 against MODE_KD: rays {n_g} / {n_k}, {differ} of 40000 pixels differ, radiance RMSE {rmse:.2e}")
+    assert abs(n_g - n_k) <= max(2, n_k // 100000)
+    assert rmse <= RMSE_TOL and differ <= 400  # 80 pixels, 4.2e-4 when this was written
