@@ -222,12 +222,15 @@ int rt_scene_set_pool_bytes(rt_scene *scene, uint64_t bytes);
 int rt_render_device(rt_scene *scene, const rt_render_params *params, double *d_rgb_accum,
                      uint64_t *ray_count, rt_render_stats *stats, void *stream);
 
-/* rt_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arithmetic, same kernels and the same results as
+/* rt_render_device for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc in the hot
+ * path, processes whose device memory is spoken for).  NO COUNTERPART IN THE REFERENCE.  BLOCKING like rt_render_device:
+ * the call synchronises the stream after every batch (batch sizes follow counters read back from the device), so it
+ * cannot be recorded into a HIP graph -- a caller under stream capture must end the capture first.  Same arithmetic, same kernels and the same results as
  * rt_render_device, but the wavefront pools, counters and tile list live in a static device array of
  * RT_NOALLOC_SCRATCH_BYTES inside the library (one copy per GPU the library runs on, held until the process ends)
  * instead of the scene's hipMalloc'ed pool budget: the call allocates and frees nothing (no hipMalloc / hipFree, no
- * events; no statistics are offered).  Limits: at most RT_NOALLOC_MAX_CAMERA_RAYS camera rays per call (window pixels
+ * events; the counters come back into pinned host memory allocated once per device at rt_scene_create; no statistics
+ * are offered).  Limits: at most RT_NOALLOC_MAX_CAMERA_RAYS camera rays per call (window pixels
  * x samples, after sharding) and 4096 tiles; larger calls fail with RT_ERR_NOMEM and a message -- split the window or
  * the sample range.  Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two host
  * threads, two streams) race; serialise them.  The array keeps the last call's contents; the library resets what must

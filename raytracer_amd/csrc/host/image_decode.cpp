@@ -75,7 +75,9 @@ struct Huff {
     }
 };
 
-bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> *out, std::string *err) {
+// max_out: what the caller can use (a PNG knows its size from IHDR): a stream that inflates beyond it is refused instead of
+// being allowed to grow without bound (a few KB of IDAT can describe gigabytes).
+bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> *out, size_t max_out, std::string *err) {
     if (in.size() < 6 || (in[0] & 0x0F) != 8 || ((in[0] << 8) | in[1]) % 31 != 0 || (in[1] & 0x20)) {
         *err = "bad zlib header";
         return false;
@@ -86,6 +88,10 @@ bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> *out, std
     static const uint16_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     BitReader br(in.data() + 2, in.data() + in.size());
     for (bool last = false; !last;) {
+        if (out->size() > max_out) {
+            *err = "compressed data inflates beyond the image's size";
+            return false;
+        }
         last = br.bits(1) != 0;
         const uint32_t type = br.bits(2);
         if (br.bad) break;
@@ -158,6 +164,10 @@ bool inflate_zlib(const std::vector<uint8_t> &in, std::vector<uint8_t> *out, std
         }
         bool block_ok = false;
         while (true) {
+            if (out->size() > max_out) {
+                *err = "compressed data inflates beyond the image's size";
+                return false;
+            }
             const int sym = lit.decode(br);
             if (sym < 0) break;
             if (sym < 256) {
@@ -236,10 +246,10 @@ bool decode_png(const std::vector<uint8_t> &f, uint32_t *w_out, uint32_t *h_out,
         *err = "unsupported PNG bit depth";
         return false;
     }
-    std::vector<uint8_t> raw;
-    if (!inflate_zlib(idat, &raw, err)) return false;
     const size_t bpp = static_cast<size_t>(std::max(1, channels * depth / 8));  // filter unit
     const size_t stride = (static_cast<size_t>(w) * channels * depth + 7) / 8;
+    std::vector<uint8_t> raw;
+    if (!inflate_zlib(idat, &raw, (stride + 1) * h, err)) return false;
     if (raw.size() < (stride + 1) * h) {
         *err = "truncated PNG image data";
         return false;
@@ -531,6 +541,12 @@ bool decode_jpeg(const std::vector<uint8_t> &f, uint32_t *w_out, uint32_t *h_out
                 *err = "unsupported JPEG frame (components)";
                 return false;
             }
+            // the planes are allocated from the header before any entropy data is seen: a frame needs at least a bit of
+            // data per 8x8 block (a 65535 x 65535 header on a few bytes would ask for 12 GB)
+            if (static_cast<uint64_t>(width) * height / 64 / 8 > f.size()) {
+                *err = "JPEG frame size does not fit the file's size";
+                return false;
+            }
             for (int c = 0; c < nc; ++c) {
                 comp[c].id = d[6 + 3 * c];
                 comp[c].h = d[7 + 3 * c] >> 4;
@@ -599,8 +615,15 @@ bool decode_jpeg(const std::vector<uint8_t> &f, uint32_t *w_out, uint32_t *h_out
                                     return false;
                                 }
                                 comp[c].pred += jextend(br.receive(t), t);
+                                if (comp[c].pred < -32768 || comp[c].pred > 32767) {  // a DC value is 11 bits in a baseline file (T.81 F.1.2.1)
+                                    *err = "corrupt JPEG entropy data (DC out of range)";
+                                    return false;
+                                }
                                 const uint16_t *q = qt[comp[c].tq];
-                                blk[0] = comp[c].pred * q[0];
+                                // a dequantised coefficient of 8-bit samples is within +-1,200; beyond +-16,384 (corrupt data, 16-bit
+                                // tables) the fixed-point IDCT's int products would overflow
+                                auto dequant = [](int v, int qv) { return std::max(-16384, std::min(16384, v * qv)); };
+                                blk[0] = dequant(comp[c].pred, q[0]);
                                 for (int k = 1; k < 64;) {
                                     const int rs = jdecode(br, hac[comp[c].ta]);
                                     if (rs < 0) {
@@ -618,12 +641,18 @@ bool decode_jpeg(const std::vector<uint8_t> &f, uint32_t *w_out, uint32_t *h_out
                                         *err = "corrupt JPEG entropy data";
                                         return false;
                                     }
-                                    blk[zigzag[k]] = jextend(br.receive(s), s) * q[zigzag[k]];
+                                    blk[zigzag[k]] = dequant(jextend(br.receive(s), s), q[zigzag[k]]);
                                     ++k;
                                 }
                                 const int px = (x * comp[c].h + bx) * 8, py = (y * comp[c].v + by) * 8, stride = comp[c].bw * 8;
                                 idct_block(blk, &comp[c].plane[static_cast<size_t>(py) * stride + px], stride);
                             }
+                    // the reader ran into a marker (it feeds zeros from there on) with MCUs of this interval still to come: the
+                    // file is truncated -- stop, instead of decoding up to 67 million MCUs of zeros for a 65535 x 65535 header
+                    if (br.marker && !(y == my - 1 && x == mx - 1) && !(restart && todo == 1)) {
+                        *err = "truncated JPEG entropy data";
+                        return false;
+                    }
                     if (restart && --todo == 0 && !(y == my - 1 && x == mx - 1)) {  // RSTn: byte-align, skip the marker, reset predictors
                         const uint8_t *q = br.p;
                         while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;

@@ -547,6 +547,9 @@ int plan_call(rt_scene *s, RenderCtx &c, const rt_render_params *prm, CallPlan *
         plan->wl.s0 = s0;
         plan->wl.ns = s1 - s0;
         plan->wl.seed = p.seed;
+        c.plan_wl.s0 = s0;  // the cached work list stays the last call's (rt_render_progressive reads it back)
+        c.plan_wl.ns = s1 - s0;
+        c.plan_wl.seed = p.seed;
         plan->total_items = static_cast<uint64_t>(plan->wl.n_tiles) * plan->wl.tile_w * plan->wl.tile_h * plan->wl.ns;
         if (plan->total_items > 0xFFFFFFFFull) return fail(RT_ERR_INVALID, "more than 2^32 camera rays in one call");
         if (c.plan_scattered == (first_batch_items(c, plan->total_items, plan->wl.ns) < plan->total_items)) return RT_OK;
@@ -648,7 +651,7 @@ constexpr int MAX_DEVICES = 64;
 struct FixedCtx {
     void *ptr = nullptr;  // this device's address of `scratch`
     RenderCtx ctx;        // carved from it once
-    Counters h_ctr[MAX_SHARDS];
+    Counters *h_ctr = nullptr;  // pinned host copy of the counters, allocated once (set-up), kept until the process ends
 };
 FixedCtx g_fixed[MAX_DEVICES];
 std::mutex g_fixed_mutex;
@@ -668,6 +671,7 @@ int scratch_for_device(int device, void **out) {
         c.d_tiles = reinterpret_cast<uint32_t *>(base + SCRATCH_CTR_BYTES);
         c.d_tiles_cap = SCRATCH_MAX_TILES;
         c.can_grow = false;
+        if (!f.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&f.h_ctr), MAX_SHARDS * sizeof(Counters)));
         c.h_ctr = f.h_ctr;
         if (int rc = carve_pools(base + SCRATCH_CTR_BYTES + SCRATCH_TILE_BYTES, SCRATCH_POOL_BYTES, &c.np, &c.gp)) return rc;
         f.ptr = ptr;
@@ -900,10 +904,18 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
                 for (int k = 0; k < 3; ++k)
                     if (!std::isfinite(cull_boxes[b].mn[k]) || !std::isfinite(cull_boxes[b].mx[k])) on_device = false;
         }
+        bvhdev::DeviceBuildResult dr;
         if (on_device && n_bounded > 0) {
-            bvhdev::DeviceBuildResult dr;
             std::string why;
-            if (!bvhdev::build_bvh_device(cull_boxes, leaf_group, &dr, &why)) return fail(RT_ERR_DEVICE, "device BVH build: " + why);
+            if (!bvhdev::build_bvh_device(cull_boxes, leaf_group, &dr, &why)) {
+                // a tree deeper than the traversal stack, or a HIP error of the builder: the host builder takes over (a
+                // device that is really gone fails at the uploads below)
+                (void)hipGetLastError();
+                if (timing) std::fprintf(stderr, "rt_scene_create:   device BVH build gave up (%s): host builder\n", why.c_str());
+                on_device = false;
+            }
+        }
+        if (on_device && n_bounded > 0) {
             if (dr.d_nodes) sc->allocs.push_back(const_cast<BvhNode *>(dr.d_nodes));
             d_built_nodes = dr.d_nodes;
             n_built_nodes = dr.n_nodes;
@@ -1583,7 +1595,8 @@ int rt_render_progressive(rt_scene *s, const rt_render_params *params, uint32_t 
             const WorkList &wl = s->ctx.plan_wl;
             const uint64_t npx = static_cast<uint64_t>(wl.n_tiles) * wl.tile_w * wl.tile_h;
             if (npx)
-                hipLaunchKernelGGL(k_tonemap_argb_tiles, dim3(grid_1d(npx, 2048)), dim3(BLOCK), 0, nullptr, s->dev, wl, wl.ns, acc.as<double>(), img.as<uint32_t>());
+                hipLaunchKernelGGL(k_tonemap_argb_tiles, dim3(grid_1d(npx, 2048)), dim3(BLOCK), 0, nullptr, s->dev, wl, s->dev.opts.samples_per_pixel, acc.as<double>(),
+                                   img.as<uint32_t>());  // the divisor is the scene's sample count, as in rt_render's rgba8 (:614), whatever range this call rendered
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpy(argb, img.p, n * 4, hipMemcpyDeviceToHost));
             if (on_pass && on_pass(user, pass + 1, n_passes, rays) != 0) break;  // the caller closed its window (:865)
@@ -1804,12 +1817,19 @@ int render_multi_impl(rt_scene *const *scenes, uint32_t n, const rt_render_param
     std::vector<uint64_t> rays(n, 0);
     std::vector<std::thread> pool;
     pool.reserve(n);
-    for (uint32_t i = 0; i < n; ++i)
-        pool.emplace_back([&, i] {
-            rcs[i] = guarded([&]() -> int { return multi_shard(scenes[i], root, i, n, base, d_rgb_accum, stream, &rays[i], stats ? stats + i : nullptr); });
-            if (rcs[i]) errs[i] = g_error;
-        });
+    bool spawn_failed = false;
+    for (uint32_t i = 0; i < n && !spawn_failed; ++i) {
+        try {
+            pool.emplace_back([&, i] {
+                rcs[i] = guarded([&]() -> int { return multi_shard(scenes[i], root, i, n, base, d_rgb_accum, stream, &rays[i], stats ? stats + i : nullptr); });
+                if (rcs[i]) errs[i] = g_error;
+            });
+        } catch (...) {  // std::system_error (no more threads) / bad_alloc: the threads already running must be joined before
+            spawn_failed = true;  // anything unwinds, or their destructors terminate the process
+        }
+    }
     for (auto &t : pool) t.join();
+    if (spawn_failed) return fail(RT_ERR_NOMEM, "rt_render_multi: could not start a host thread per scene");
     for (uint32_t i = 0; i < n; ++i)
         if (rcs[i]) return fail(rcs[i], "rt_render_multi, scene " + std::to_string(i) + ": " + errs[i]);
     // exchange step, root side: every other shard's tiles are in its inbox on this device

@@ -309,6 +309,42 @@ def test_texture_decoders_jpeg(libs, tmp_path):
         host.image_load(str(tmp_path / "prog.jpg"))
 
 
+def test_texture_decoders_refuse_hostile_files(libs, tmp_path):
+    """Texture files are untrusted input: a PNG whose few KB of IDAT inflate far beyond the image IHDR describes, a
+    JPEG cut off in its entropy data, and a JPEG header that asks for gigabytes on a few bytes are errors, promptly."""
+    import struct
+    import time
+    import zlib
+
+    from PIL import Image
+
+    host, _ = libs
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data))
+
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * (64 << 20), 9)) + chunk(b"IEND", b"")
+    assert len(bomb) < 100000
+    open(tmp_path / "bomb.png", "wb").write(bomb)
+    t0 = time.perf_counter()
+    with pytest.raises(host.HostError, match="inflates beyond"):
+        host.image_load(str(tmp_path / "bomb.png"))
+    assert time.perf_counter() - t0 < 1.0
+    rng = np.random.default_rng(5)
+    Image.fromarray(rng.integers(0, 256, size=(256, 256, 3), dtype=np.uint8)).save(str(tmp_path / "full.jpg"), quality=90)
+    data = open(tmp_path / "full.jpg", "rb").read()
+    open(tmp_path / "cut.jpg", "wb").write(data[: len(data) // 3] + b"\xff\xd9")
+    with pytest.raises(host.HostError, match="truncated JPEG"):
+        host.image_load(str(tmp_path / "cut.jpg"))
+    sof = data.index(b"\xff\xc0")
+    huge = data[: sof + 5] + b"\xff\xff\xff\xff" + data[sof + 9:]  # height = width = 65535
+    open(tmp_path / "huge.jpg", "wb").write(huge)
+    t0 = time.perf_counter()
+    with pytest.raises(host.HostError, match="does not fit the file"):
+        host.image_load(str(tmp_path / "huge.jpg"))
+    assert time.perf_counter() - t0 < 1.0
+
+
 def test_scene_textures_come_from_the_in_tree_decoder(libs):
     """The loader hands rt_scene_create the decoder's texels (no pre-decoded sidecar files any more)."""
     host, _ = libs

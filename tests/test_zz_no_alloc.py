@@ -10,13 +10,17 @@ from conftest import load_scene
 pytestmark = pytest.mark.gpu
 
 
-def _both(gpu, torch, abi, params, h, w):
+def _both(gpu, torch, abi, params, h, w, check_free=False):
     ref = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
     out = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
     torch.cuda.synchronize()
     n_ref, _ = gpu.render_device(ref.data_ptr(), params, want_stats=False)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]  # hipMemGetInfo: free bytes of the device
     n_out = gpu.render_device_noalloc(out.data_ptr(), params)
     torch.cuda.synchronize()
+    if check_free:  # "allocates nothing": the device's free memory is what it was (not on a process's first call, which loads code)
+        assert torch.cuda.mem_get_info()[0] == free_before
     return ref.cpu().numpy(), out.cpu().numpy(), n_ref, n_out
 
 
@@ -35,7 +39,7 @@ def test_noalloc_matches_render_device_twice():
     assert np.array_equal(a_ref, a_out)
     # second call, smaller input (a window, two of the four samples): the scratch still holds the first call's contents
     p = abi.RenderParams(seed=3, x0=40, y0=24, x1=104, y1=72, s0=1, s1=3)
-    b_ref, b_out, m_ref, m_out = _both(gpu, torch, abi, p, 160, 160)
+    b_ref, b_out, m_ref, m_out = _both(gpu, torch, abi, p, 160, 160, check_free=True)
     assert m_ref == m_out and 0 < m_ref < n_ref
     assert np.array_equal(b_ref, b_out)
     assert not b_out[:24].any() and not b_out[:, :40].any() and b_out[24:72, 40:104].any()
@@ -45,7 +49,7 @@ def test_noalloc_matches_render_device_twice():
     c_ref, c_out, k_ref, k_out = _both(gpu2, torch, abi, abi.RenderParams(shard_index=1, shard_count=3, tile_size=8), 96, 96)
     assert k_ref == k_out and np.array_equal(c_ref, c_out)
     # and the first scene again
-    d_ref, d_out, _, _ = _both(gpu, torch, abi, p, 160, 160)
+    d_ref, d_out, _, _ = _both(gpu, torch, abi, p, 160, 160, check_free=True)
     assert np.array_equal(d_out, b_out) and np.array_equal(d_ref, b_ref)
 
 
