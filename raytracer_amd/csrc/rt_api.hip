@@ -302,6 +302,17 @@ struct rt_scene {
     int n_cus = 256;
     bool bvh_on_device = false;  // the tree was built by rt_bvh_device.hip.h
     GiTune gi_tune;  // rt_tune.h
+    // Side streams of a render call (created once, at the scene's first render that uses them): after k_expand(level) three
+    // launches are independent -- the level's GI rays (k_trace_gi, caller's stream), the closest-hit rays of the children
+    // it emitted (stream 0) and the shadow rays of its jobs (stream 1) -- and each one's tail (a launch cannot end before
+    // its longest ray) is filled by the others' blocks.
+    struct Side {
+        hipStream_t stream[2] = {nullptr, nullptr};
+        hipEvent_t expanded[MAX_LEVELS + 1] = {};  // caller's stream: k_close_expand(level) done
+        hipEvent_t traced[MAX_LEVELS + 1] = {};    // stream 0: the children of `level` are traced
+        hipEvent_t shadows = nullptr;              // stream 1: every shadow launch done
+        bool ready = false;
+    } side;
 
     uint64_t pool_bytes = 24ull << 30;  // upper limit of the wavefront pools; 8 % of the 288 GB
     bool pool_explicit = false;         // set by rt_scene_set_pool_bytes: take it as it is
@@ -336,6 +347,13 @@ struct rt_scene {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != device) hipSetDevice(device);
         for (void *p : allocs) hipFree(p);
+        for (hipStream_t st : side.stream)
+            if (st) hipStreamDestroy(st);
+        for (uint32_t l = 0; l <= MAX_LEVELS; ++l) {
+            if (side.expanded[l]) hipEventDestroy(side.expanded[l]);
+            if (side.traced[l]) hipEventDestroy(side.traced[l]);
+        }
+        if (side.shadows) hipEventDestroy(side.shadows);
         if (pool_mem) hipFree(pool_mem);
         if (ctx.d_ctr) hipFree(ctx.d_ctr);
         if (ctx.h_ctr) hipHostFree(ctx.h_ctr);
@@ -423,6 +441,20 @@ int ensure_pools(rt_scene *s) {
     if (!ctx.h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx.h_ctr), MAX_SHARDS * sizeof(Counters)));
     ctx.forget_estimates();
     ctx.plan_valid = false;
+    return RT_OK;
+}
+
+int ensure_side_streams(rt_scene *s) {
+    rt_scene::Side &sd = s->side;
+    if (sd.ready) return RT_OK;
+    for (hipStream_t &st : sd.stream)
+        if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (uint32_t l = 0; l <= MAX_LEVELS; ++l) {
+        if (!sd.expanded[l]) HIP_TRY(hipEventCreateWithFlags(&sd.expanded[l], hipEventDisableTiming));
+        if (!sd.traced[l]) HIP_TRY(hipEventCreateWithFlags(&sd.traced[l], hipEventDisableTiming));
+    }
+    if (!sd.shadows) HIP_TRY(hipEventCreateWithFlags(&sd.shadows, hipEventDisableTiming));
+    sd.ready = true;
     return RT_OK;
 }
 
@@ -1225,6 +1257,22 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     gi_timer.enabled = gi_tuning && gi_can_qualify && !stats;  // with stats the main timer has the figure
     gi_timer.stream = stream;
     gi_timer.chaining = false;
+    // Overlap (rt_scene::Side): where launches have tails worth filling -- a tree too large for LDS / L1 (rays wait on memory:
+    // mesh_test.json, 41 K triangles, 10.0 -> 8.4 ms; mesh.json -2 %) or a call of a fraction of a frame (a 1/8 shard of
+    // scene.json 3.13 -> 2.99 ms).  A whole frame of a small scene is bound by VALU issue in every one of the three launches
+    // and gains nothing (scene.json 17.0 ms either way): it stays on the caller's stream, one kernel at a time.  The scene's
+    // own context only, once its switches are settled (while they are being tried out the closest-hit kernels are timed one
+    // after the other).  MI355RT_OVERLAP=0 / 1 forces either.
+    static const char *overlap_env = std::getenv("MI355RT_OVERLAP");
+    const bool overlap_wanted = overlap_env ? std::strcmp(overlap_env, "0") != 0 : (s->dev.n_bounded >= 4096 || plan.total_items <= 655360);
+    const bool overlap = overlap_wanted && &ctx == &s->ctx && !gi_tuning && max_depth > 0;
+    if (overlap)
+        if ((rc = ensure_side_streams(s))) return rc;
+    EventTimer timer_side[2], timer_off;  // spans of the launches on the side streams; timer_off: never enabled
+    for (int q = 0; q < 2; ++q) {
+        timer_side[q].enabled = stats != nullptr && overlap;
+        timer_side[q].stream = overlap ? s->side.stream[q] : nullptr;
+    }
     double gi_ms = 0.0;
     uint64_t gi_rays_call = 0, tune_rays_call = 0;
     EventPair call_ev;
@@ -1261,30 +1309,59 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         hipLaunchKernelGGL(k_raygen, dim3(shard_grid(s, sh, n, 8)), dim3(BLOCK), 0, stream, s->dev, wl, np, d_ctr, sh, i0, n32);
         timer.end();
         if (max_depth > 0) {
-            for (uint32_t level = 0; level < max_depth; ++level) {
+            // closest-hit launch over the nodes of `level` (`what`: all of them, or the children k_expand(level - 1) emitted) and,
+            // where the last traced level's illumination nodes take two-phase queries over the emissive set, their kernel
+            auto launch_closest = [&](uint32_t level, uint32_t what, hipStream_t on, EventTimer &t, EventTimer &t_tune) {
                 const uint32_t g = level == 0 ? shard_grid(s, sh, n, 48) : g_level;
-                // the last traced level's illumination nodes take two-phase queries over the emissive set, in a kernel of their own
                 const uint32_t illum_apart = level > 0 && level + 1 == max_depth && (s->dev.gi_two_phase & 4u) && s->dev.special[1].ok ? 1u : 0u;
-                timer.begin(CLS_CLOSEST);
-                gi_timer.begin(CLS_CLOSEST);
-                if (count_work) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s), illum_apart);
-                else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s), illum_apart);
-                timer.end();
-                gi_timer.end();
+                t.begin(CLS_CLOSEST);
+                t_tune.begin(CLS_CLOSEST);
+                if (count_work) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), on, s->dev, np, d_ctr, sh, level, stack_entries(s), illum_apart, what);
+                else hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(g), dim3(BLOCK), stack_lds_bytes(s), on, s->dev, np, d_ctr, sh, level, stack_entries(s), illum_apart, what);
+                t.end();
+                t_tune.end();
                 if (illum_apart) {
-                    timer.begin(CLS_ILLUM);
-                    gi_timer.begin(CLS_ILLUM);
+                    t.begin(CLS_ILLUM);
+                    t_tune.begin(CLS_ILLUM);
                     auto *kern = count_work ? (gi_waves3 ? k_trace_illum_last<true, 3> : k_trace_illum_last<true, 4>) : (gi_waves3 ? k_trace_illum_last<false, 3> : k_trace_illum_last<false, 4>);
-                    hipLaunchKernelGGL(kern, dim3(g), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, np, d_ctr, sh, level, stack_entries(s));
-                    timer.end();
-                    gi_timer.end();
+                    hipLaunchKernelGGL(kern, dim3(g), dim3(BLOCK), stack_lds_bytes(s), on, s->dev, np, d_ctr, sh, level, stack_entries(s), what);
+                    t.end();
+                    t_tune.end();
+                }
+            };
+            auto launch_shadow = [&](uint32_t what, uint32_t level, hipStream_t on, EventTimer &t) {
+                t.begin(CLS_SHADOW);
+                if (count_work) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), on, s->dev, gp, d_ctr, sh, stack_entries(s), what, level);
+                else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), on, s->dev, gp, d_ctr, sh, stack_entries(s), what, level);
+                t.end();
+            };
+            for (uint32_t level = 0; level < max_depth; ++level) {
+                if (level == 0 || !overlap) launch_closest(level, MAP_NODES, stream, timer, gi_timer);
+                else {  // the children were traced beside k_trace_gi(level)
+                    HIP_TRY(hipStreamWaitEvent(stream, s->side.traced[level], 0));
+                    timer.chain = false;
                 }
                 timer.begin(CLS_EXPAND);
                 hipLaunchKernelGGL(k_build_live, dim3(level == 0 ? shard_grid(s, sh, n / 4 + 1, 8) : g_wide), dim3(BLOCK), 0, stream, np, d_ctr, sh, level);
                 const uint32_t ge = level == 0 ? shard_grid(s, sh, n, 8) : g_wide;
                 if (count_work) hipLaunchKernelGGL(k_expand<true>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, gp, d_ctr, sh, level);
                 else hipLaunchKernelGGL(k_expand<false>, dim3(ge), dim3(BLOCK), 0, stream, s->dev, wl, np, gp, d_ctr, sh, level);
-                timer.end();
+                if (overlap) {  // what k_expand emitted is final: its children and its jobs can be traced beside the level's GI rays
+                    hipLaunchKernelGGL(k_close_expand, dim3(1), dim3(64), 0, stream, d_ctr, sh, level);
+                    timer.end();
+                    HIP_TRY(hipEventRecord(s->side.expanded[level], stream));
+                    timer.chain = false;  // an event of another kind sits between this span and the next
+                    if (level + 1 < max_depth) {
+                        HIP_TRY(hipStreamWaitEvent(s->side.stream[0], s->side.expanded[level], 0));
+                        launch_closest(level + 1, MAP_CHILDREN, s->side.stream[0], timer_side[0], timer_off);
+                        HIP_TRY(hipEventRecord(s->side.traced[level + 1], s->side.stream[0]));
+                        timer_side[0].chain = false;
+                    }
+                    HIP_TRY(hipStreamWaitEvent(s->side.stream[1], s->side.expanded[level], 0));
+                    launch_shadow(MAP_LEVEL_JOBS, level, s->side.stream[1], timer_side[1]);
+                } else {
+                    timer.end();
+                }
                 if (level + 1 < max_depth && gi_rays_host(s->dev.opts, level) <= GI_MAX_INPLACE) {  // the GI rays of this level's hits, in place
                     timer.begin(CLS_GI);
                     gi_timer.begin(CLS_GI);
@@ -1301,10 +1378,13 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
                 hipLaunchKernelGGL(k_advance_level, dim3(1), dim3(64), 0, stream, d_ctr, sh, level);
                 timer.end();
             }
-            timer.begin(CLS_SHADOW);
-            if (count_work) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, gp, d_ctr, sh, stack_entries(s));
-            else hipLaunchKernelGGL(k_trace_shadow<false>, dim3(g_level), dim3(BLOCK), stack_lds_bytes(s), stream, s->dev, gp, d_ctr, sh, stack_entries(s));
-            timer.end();
+            if (overlap) {
+                HIP_TRY(hipEventRecord(s->side.shadows, s->side.stream[1]));
+                HIP_TRY(hipStreamWaitEvent(stream, s->side.shadows, 0));
+                timer.chain = false;
+            } else {
+                launch_shadow(MAP_JOBS, 0u, stream, timer);
+            }
             for (uint32_t level = max_depth; level-- > 0;) {
                 timer.begin(CLS_RESOLVE);
                 const dim3 gr(level == 0 ? shard_grid(s, sh, n, 8) : g_wide);
@@ -1361,6 +1441,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         uint32_t cls_n[CLS_COUNT] = {0};
         timer.collect(cls_ms, cls_n, CLS_COUNT);
         gi_timer.collect(cls_ms, cls_n, CLS_COUNT);  // only one of the two timers runs
+        for (EventTimer &t : timer_side) t.collect(cls_ms, cls_n, CLS_COUNT);  // launches that ran beside others: their spans overlap the caller's stream's
         if (c.overflow) {
             if (n <= wl.ns) return fail(RT_ERR_NOMEM, "pool budget too small for one pixel's ray tree");
             batch = std::max<uint64_t>(wl.ns, (n / 2) - (n / 2) % wl.ns);

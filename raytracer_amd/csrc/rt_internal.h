@@ -232,6 +232,8 @@ struct Counters {
     unsigned long long job_alloc;      // bump pointer into the shard's GI jobs
     unsigned long long special_alloc;  // bump pointer into the shard's GI specials
     uint32_t job_level_start[MAX_LEVELS + 1];  // jobs left by k_expand(level): [job_level_start[level], job_alloc) until the level is closed
+    uint32_t child_end[MAX_LEVELS + 1];        // node_alloc when k_expand(level - 1) had finished: the children it emitted are
+                                               // [level_start[level - 1] + level_count[level - 1], child_end[level]) (k_close_expand)
     unsigned long long gi_rays;          // GI rays traced in place
     unsigned long long gi_materialised;  // of which got a node (also counted in level_count)
     unsigned long long illum_last_rays;  // illumination nodes of the last traced level answered by k_trace_illum_last

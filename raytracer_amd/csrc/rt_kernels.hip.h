@@ -90,16 +90,34 @@ struct LevelMap {
     uint32_t dead;                    // some shard overflowed: the batch will be re-run, do nothing
 };
 // All threads of the block call it (one __syncthreads inside); returns the number of groups.
-// job_list: the entries are the jobs of all levels (k_trace_shadow) instead of the nodes of `level`.
+// What the entries of a work map are:
+//   MAP_NODES      the nodes of `level` (closed by k_advance_level(level - 1))
+//   MAP_CHILDREN   the nodes of `level` that k_expand(level - 1) emitted (closed by k_close_expand(level - 1)): what a
+//                  closest-hit launch can trace while k_trace_gi(level) is still appending the level's other nodes
+//   MAP_JOBS       the jobs of all levels
+//   MAP_LEVEL_JOBS the jobs k_expand(level) left (closed by k_close_expand(level))
+enum : uint32_t { MAP_NODES = 0, MAP_CHILDREN = 1, MAP_JOBS = 2, MAP_LEVEL_JOBS = 3 };
 __device__ __forceinline__ uint32_t level_map_build(LevelMap &m, const Counters *ctrs, const Shards &sh, uint32_t level,
-                                                   bool job_list) {
+                                                   uint32_t what) {
     if (threadIdx.x < 64u) {
         const uint32_t k = threadIdx.x;
         uint32_t cnt = 0, over = 0;
         if (k < sh.count) {
-            cnt = job_list ? static_cast<uint32_t>(ctrs[k].job_alloc) : ctrs[k].level_count[level];
             over = ctrs[k].overflow;
-            m.base[k] = job_list ? k * sh.job_cap : k * sh.node_cap + ctrs[k].level_start[level];
+            if (what == MAP_NODES) {
+                cnt = ctrs[k].level_count[level];
+                m.base[k] = k * sh.node_cap + ctrs[k].level_start[level];
+            } else if (what == MAP_CHILDREN) {
+                const uint32_t start = ctrs[k].level_start[level - 1u] + ctrs[k].level_count[level - 1u];
+                cnt = over ? 0u : ctrs[k].child_end[level] - start;
+                m.base[k] = k * sh.node_cap + start;
+            } else if (what == MAP_JOBS) {
+                cnt = static_cast<uint32_t>(ctrs[k].job_alloc);
+                m.base[k] = k * sh.job_cap;
+            } else {
+                cnt = over ? 0u : ctrs[k].job_level_start[level + 1u] - ctrs[k].job_level_start[level];
+                m.base[k] = k * sh.job_cap + ctrs[k].job_level_start[level];
+            }
             m.count[k] = cnt;
         }
         uint32_t x = (cnt + 63u) / 64u;
@@ -337,7 +355,7 @@ __global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
     ctr->shadow_rays = 0;
     ctr->job_alloc = 0;
     ctr->special_alloc = 0;
-    for (uint32_t i = 0; i <= MAX_LEVELS; ++i) ctr->job_level_start[i] = 0;
+    for (uint32_t i = 0; i <= MAX_LEVELS; ++i) ctr->job_level_start[i] = ctr->child_end[i] = 0;
     ctr->gi_rays = ctr->gi_materialised = ctr->illum_last_rays = 0;
     ctr->overflow = local > sh.node_cap ? 1u : 0u;
     ctr->active_camera = 0;
@@ -348,6 +366,19 @@ __global__ void k_begin_batch(Counters *ctrs, Shards sh, uint32_t n_items) {
     ctr->wave_node_steps = ctr->wave_leaf_rounds = ctr->wave_iterations = ctr->wave_max_steps = 0;
     for (uint32_t q = 0; q < 16; ++q) ctr->leaf_census[q] = 0;
     for (uint32_t q = 0; q < 4; ++q) ctr->leaf_lanes[q] = 0;
+}
+
+// After k_expand(level): what it emitted is final -- its children [.., child_end[level + 1]) and its jobs
+// [job_level_start[level], job_level_start[level + 1]) -- while the level's nodes as a whole are not (k_trace_gi(level + 1)
+// appends the GI rays that need nodes; k_advance_level closes the level after it).  Lets the closest-hit launch over the
+// children and the shadow launch over the jobs run beside k_trace_gi on streams of their own.
+__global__ void k_close_expand(Counters *ctrs, Shards sh, uint32_t level) {
+    const uint32_t k = threadIdx.x;
+    if (blockIdx.x != 0 || k >= sh.count) return;
+    Counters *ctr = ctrs + k;
+    if (ctr->node_alloc > sh.node_cap || ctr->job_alloc > sh.job_cap) ctr->overflow = 1;
+    ctr->child_end[level + 1] = static_cast<uint32_t>(ctr->node_alloc);
+    ctr->job_level_start[level + 1] = static_cast<uint32_t>(ctr->job_alloc);
 }
 
 __global__ void k_advance_level(Counters *ctrs, Shards sh, uint32_t level) {
@@ -404,7 +435,7 @@ __device__ __forceinline__ void live_scan(const NodePool &np, Counters *ctrs, ui
 }
 __global__ __launch_bounds__(BLOCK) void k_build_live(NodePool np, Counters *ctrs, Shards shards, uint32_t level) {
     __shared__ LevelMap map;
-    if (level_map_build(map, ctrs, shards, level, false) == 0) return;
+    if (level_map_build(map, ctrs, shards, level, MAP_NODES) == 0) return;
     // Chunks of LIVE_GROUPS groups are dealt shard by shard (chunk c: shard c % K, the shard's c / K-th chunk), so the
     // waves running at any moment bump the counters of all shards, not the one or two whose groups are next in the
     // level's list: a counter word takes ~90 returning atomics a microsecond.
@@ -772,12 +803,12 @@ __device__ __forceinline__ uint32_t any_hit_before(const SceneDev &sc, const Tre
 // is 80 % of all nodes.
 template <bool COUNT, bool FINALIZE>
 __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev sc, NodePool np, Counters *ctrs, Shards shards,
-                                                        uint32_t level, uint32_t stack_entries, uint32_t skip_illum = 0) {
+                                                        uint32_t level, uint32_t stack_entries, uint32_t skip_illum = 0, uint32_t what = MAP_NODES) {
     extern __shared__ __align__(16) uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;
     __shared__ LevelMap map;
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
-    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
+    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, what);
     if (blockIdx.x * (BLOCK / 64) >= n_groups) return;  // no group for this block: leave before staging the tree (the small launches of the deep levels)
     const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     unsigned long long n_nodes = 0, n_prims = 0;
@@ -1004,12 +1035,12 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
 // colour nodes of the level stay with k_trace_closest (launched with skip_illum).  physical.json: 164 M of these.
 template <bool COUNT, int WAVES>
 __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_illum_last(SceneDev sc, NodePool np, Counters *ctrs, Shards shards, uint32_t level,
-                                                                 uint32_t stack_entries) {
+                                                                 uint32_t stack_entries, uint32_t what) {
     extern __shared__ __align__(16) uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;
     __shared__ LevelMap map;
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
-    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, false);
+    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, what);
     if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
     const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     unsigned long long n_nodes = 0, n_prims = 0;
@@ -1103,13 +1134,14 @@ __device__ __forceinline__ bool any_hit(const SceneDev &sc, const TreeView &tv, 
 // every lane starts with a ray whatever the masks hold; a stopped ray sets its light's bit in the job's word through
 // LDS, and the job's lane stores the word.
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc, GiPool gp, Counters *ctrs, Shards shards, uint32_t stack_entries) {
+__global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc, GiPool gp, Counters *ctrs, Shards shards, uint32_t stack_entries, uint32_t what,
+                                                                     uint32_t level) {
     extern __shared__ __align__(16) uint32_t stack_lds[];
     uint32_t *stack = stack_lds + threadIdx.x;
     __shared__ LevelMap map;
     __shared__ uint32_t s_incl[BLOCK], s_occ[BLOCK];
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
-    const uint32_t n_groups = level_map_build(map, ctrs, shards, 0u, true);
+    const uint32_t n_groups = level_map_build(map, ctrs, shards, level, what);  // MAP_JOBS: all levels at once; MAP_LEVEL_JOBS: the jobs of `level`
     if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
     const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const TreeView tree = main_tree(sc, top_nodes);
