@@ -39,6 +39,11 @@ def _gi_form(bits):
     return "two-phase queries for " + " + ".join(on) if on else "closest-hit queries"
 
 
+def gi_variant(bits, waves):
+    """The switch set of a call in words: what `roofline.gi_query_form` says and what profiles/pmc_*.json carry as `_variant`."""
+    return f"{_gi_form(bits)}, {waves} waves/SIMD"
+
+
 def algorithmic_bytes(kind, nodes_per_ray, tri_per_ray, analytic_per_ray):
     """closest-hit ray 224 B, shadow ray 136 B of wavefront
     records + 64 B per BVH2 node visited + 72 B per triangle / 104 B per
@@ -244,8 +249,16 @@ def main():
                 pmc_v = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
             except Exception:
                 pmc_t, pmc_v = {}, {}
-        src_t = f"profiles/pmc_traffic.json ({pmc_t.get('_tree', 'r01g')}), replayed" if pmc_t else None
-        src_v = f"profiles/pmc_valu.json ({pmc_v.get('_tree', 'r01g')}), replayed" if pmc_v else None
+        # ... and only if they were taken with the variant this run settled on: counters of another variant describe another kernel
+        run_variant = gi_variant(timed_stats[-1].gi_two_phase, timed_stats[-1].gi_waves) if timed_stats else ""
+        pmc_note = None
+        for name, rec in (("pmc_traffic.json", pmc_t), ("pmc_valu.json", pmc_v)):
+            if rec and rec.get("_variant") != run_variant:
+                pmc_note = f"profiles/{name} was taken with [{rec.get('_variant')}], this run settled on [{run_variant}]: not replayed"
+        if pmc_note:
+            pmc_t, pmc_v = {}, {}
+        src_t = f"profiles/pmc_traffic.json ({pmc_t.get('_tree', 'r01g')}, {pmc_t.get('_variant')}), replayed" if pmc_t else pmc_note
+        src_v = f"profiles/pmc_valu.json ({pmc_v.get('_tree', 'r01g')}, {pmc_v.get('_variant')}), replayed" if pmc_v else pmc_note
         KERNEL_OF = {"closest": "k_trace_closest", "gi": "k_trace_gi", "illum": "k_trace_illum_last", "shadow": "k_trace_shadow"}
         traffic = pmc_t.get(KERNEL_OF[kern], {}).get("hbm_bytes_per_launch")
         measured_gbs = gbs(traffic * n_launch, k_ms) if traffic else None
@@ -254,6 +267,8 @@ def main():
             v = pmc_v[KERNEL_OF[kern]]
             valu = {k: v[k] for k in ("valu_busy", "lane_use", "fp64_tflops", "fp64_frac_of_peak", "wait_share") if k in v}
             valu["source"] = src_v
+        elif pmc_note:
+            valu = {"source": pmc_note}
         # whole frame: HBM bytes of every kernel of one step (PMC, replayed) against the step's wall time
         frame_bytes = None
         if pmc_t:
@@ -280,7 +295,7 @@ def main():
             "stream_bytes_per_ray": k_stream, "algorithmic_bytes_per_ray_incl_cache": round(k_bytes, 1), "rays_per_step": int(k_rays),
             "nodes_per_ray": round(nodes_s if kern == "shadow" else nodes_c, 2),   # closest + gi rays together
             "prims_per_ray": round(prims_s if kern == "shadow" else prims_c, 2),
-            "gi_query_form": (_gi_form(timed_stats[-1].gi_two_phase) if timed_stats else "") + (f", {timed_stats[-1].gi_waves} waves/SIMD" if timed_stats else ""),
+            "gi_query_form": run_variant,
             "kernel_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
             "dominant_class": dominant,
             "valu": valu,  # co-limit: VALU issue occupancy / lane use / FP64 rate of the same kernel

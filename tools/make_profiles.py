@@ -20,26 +20,33 @@ XCDS = 8
 FP64_PEAK_TFLOPS = 78.6  # vector FP64, MI355X_MICROARCH.md
 
 
+FRAMES, SKIP = 3, 1  # frames rendered by the profiled command, and how many of the first ones are left out (cold caches, pool sizing)
+
+
 def load(paths):
+    """Sums per kernel over the dispatches of the frames that count: a pass renders FRAMES identical frames (one pinned
+    variant, one batch each), so a kernel's dispatches split evenly over them and the first SKIP shares are dropped."""
     agg = defaultdict(lambda: defaultdict(float))
-    calls = defaultdict(set)
+    n = defaultdict(int)
     for path in paths:
+        rows = defaultdict(list)
         for r in csv.DictReader(open(path)):
             m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
-            if not m:
-                continue
-            k = m.group(1)
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            calls[(k, path)].add(r["Dispatch_Id"])
-    n = defaultdict(int)
-    for (k, path), ids in calls.items():
-        n[k] = max(n[k], len(ids))
+            if m:
+                rows[m.group(1)].append((int(r["Dispatch_Id"]), r["Counter_Name"], float(r["Counter_Value"])))
+        for k, rs in rows.items():
+            ids = sorted({d for d, _, _ in rs})
+            keep = set(ids[len(ids) * SKIP // FRAMES:]) if len(ids) % FRAMES == 0 else set(ids)
+            for d, name, v in rs:
+                if d in keep:
+                    agg[k][name] += v
+            n[k] = max(n[k], len(keep))
     return agg, n
 
 
 def traffic(paths):
     agg, n = load(paths)
-    out = {"_about": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/profile_frame.py scene 2 24 on one "
+    out = {"_about": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/profile_frame.py scene 3 24 (first frame left out) on one "
                      "MI355X; counters are in KiB. hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches: FETCH_SIZE doubled "
                      "per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B). Far below the algorithmic bytes because BVH "
                      "nodes / primitives (counted at 64-128 B per visit in the algorithmic figure) are L1/L2 hits and freshly written "
@@ -52,7 +59,7 @@ def traffic(paths):
 
 def valu(paths):
     agg, n = load(paths)
-    out = {"_about": "rocprofv3 --pmc SQ_* passes over tools/profile_frame.py scene 2 24 on one MI355X (sums over both frames). "
+    out = {"_about": "rocprofv3 --pmc SQ_* passes over tools/profile_frame.py scene 3 24 on one MI355X (sums over the frames after the first). "
                      "valu_busy = 4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE/8 XCDs) (rocprof's VALUBusy); lane_use = "
                      "SQ_THREAD_CYCLES_VALU / (64*SQ_ACTIVE_INST_VALU); fp64_tflops = 64*lane_use*(2*FMA_F64 + MUL_F64 + ADD_F64 + "
                      "TRANS_F64) wave instructions / kernel time, against the 78.6 TFLOP/s vector FP64 peak; wait_share = "
@@ -80,13 +87,32 @@ def valu(paths):
 
 
 if __name__ == "__main__":
-    # usage: make_profiles.py traffic|valu [--tree TAG] CSV...   (TAG = the profiles/ prefix of the tree the passes ran on)
+    # usage: make_profiles.py traffic|valu [--tree TAG] [--variant TEXT | --cfg N] [--frames F] [--skip S] CSV...
+    #   TAG = the profiles/ prefix of the tree the passes ran on; TEXT = the switch set the passes were pinned to, in
+    #   bench.py's words (roofline.gi_query_form): bench.py replays the figures only for a run that settled on the same
     args = sys.argv[2:]
-    tree = None
-    if args and args[0] == "--tree":
-        tree, args = args[1], args[2:]
+    tree = variant = None
+    while args and args[0].startswith("--"):
+        if args[0] == "--tree":
+            tree = args[1]
+        elif args[0] == "--variant":
+            variant = args[1]
+        elif args[0] == "--cfg":  # MI355RT_GI_CFG of the passes -> the words bench.py uses for it
+            import os
+
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import gi_variant
+
+            variant = gi_variant(int(args[1]) & 7, 3 if int(args[1]) & 8 else 4)
+        elif args[0] == "--frames":
+            FRAMES = int(args[1])
+        elif args[0] == "--skip":
+            SKIP = int(args[1])
+        args = args[2:]
     out = {"traffic": traffic, "valu": valu}[sys.argv[1]](args)
     if tree:
         out["_tree"] = tree
-    out["_frames"] = 2
+    if variant:
+        out["_variant"] = variant
+    out["_frames"] = FRAMES - SKIP
     print(json.dumps(out, indent=1))
