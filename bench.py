@@ -297,6 +297,9 @@ def main():
             "prims_per_ray": round(prims_s if kern == "shadow" else prims_c, 2),
             "gi_query_form": run_variant,
             "kernel_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
+            # deep trees / fractions of a frame: the library runs a level's three traversal launches beside each other, so the
+            # class times are spans that overlap (their sum exceeds the step) and a kernel's duration is its duration in company
+            "launches_overlap": bool(timed_stats and timed_stats[-1].overlapped),
             "dominant_class": dominant,
             "valu": valu,  # co-limit: VALU issue occupancy / lane use / FP64 rate of the same kernel
             "frame": {

@@ -159,7 +159,7 @@ pub struct rt_render_stats {
     pub ms_gi: f32,
     pub gi_two_phase: u32,
     pub gi_waves: u32,
-    pub _pad_gi: u32,
+    pub overlapped: u32,
     pub gi_rays: u64,
     pub illum_rays: u64,
     pub ms_illum: f32,

@@ -191,7 +191,7 @@ typedef struct rt_render_stats {
     float ms_gi;
     uint32_t gi_two_phase; /* the form of GI query this call used: 0 = one closest-hit query; two-phase on the inner levels (bit 0) / on the last traced level (bit 1) */
     uint32_t gi_waves;     /* and the k_trace_gi build: register budget for 3 or 4 waves per SIMD */
-    uint32_t _pad_gi;
+    uint32_t overlapped;   /* 1: the launches of a level ran beside each other on streams of the library (deep trees, fractions of a frame): the per-class times below are spans that overlap, their sum exceeds ms_total */
     uint64_t gi_rays;
     /* illumination rays of the last traced level answered by k_trace_illum_last (two-phase queries; part of closest_rays,
      * their time and launches are not part of ms_closest / ms_gi) */

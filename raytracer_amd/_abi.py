@@ -145,7 +145,7 @@ class RenderStats(C.Structure):
         ("ms_gi", C.c_float),
         ("gi_two_phase", C.c_uint32),
         ("gi_waves", C.c_uint32),
-        ("_pad_gi", C.c_uint32),
+        ("overlapped", C.c_uint32),
         ("gi_rays", C.c_uint64),
         ("illum_rays", C.c_uint64),
         ("ms_illum", C.c_float),

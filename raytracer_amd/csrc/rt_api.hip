@@ -526,7 +526,9 @@ int plan_tiles(const rt_render_options &o, const rt_render_params *prm, std::vec
 uint64_t first_batch_items(const RenderCtx &c, uint64_t total_items, uint32_t ns) {
     uint64_t batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, c.np.capacity / c.guess_nodes_per_item));
     const double fit = c.fit_items();
-    if (fit > 0.0) batch = std::min<uint64_t>(total_items, std::max<uint64_t>(ns, static_cast<uint64_t>(0.7 * fit)));
+    // a call like the last one (the same window or another shard of it: expansions within a few per cent) goes in ONE batch if
+    // it fits with a tenth to spare; else batches of 0.7 x what fits, the margin between the parts of an image
+    if (fit > 0.0) batch = static_cast<double>(total_items) <= 0.9 * fit ? total_items : std::min<uint64_t>(total_items, std::max<uint64_t>(ns, static_cast<uint64_t>(0.7 * fit)));
     return batch;
 }
 
@@ -1515,6 +1517,7 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     st.ray_count = st.closest_rays + st.shadow_rays;
     st.gi_two_phase = gi_cfg & 7u;
     st.gi_waves = gi_waves3 ? 3u : 4u;
+    st.overlapped = overlap ? 1u : 0u;
     if (stats) {
         HIP_TRY(hipEventRecord(call_ev.b, stream));
         HIP_TRY(hipEventSynchronize(call_ev.b));
