@@ -376,8 +376,8 @@ namespace {
 // Pool shares.  With the GI and shadow rays traced in place a frame's nodes are the camera rays, reflection / refraction
 // children and the 1-in-10 GI rays that go on (scene.json: 21 M nodes, 16 M jobs -- one per colour node that is lit or
 // casts GI rays --, 7 M specials).  Per node: ray 64 + hit 28 + expansion info 16 + live 4 = 112 bytes; three quarters of
-// a job of 80 bytes; one special of 8 bytes (+ 8 of alignment slack).  Batches are sized from the measured use of every pool.
-constexpr uint64_t POOL_BYTES_PER_NODE = 112 + 60 + 8 + 8;
+// a job of 80 bytes and of its 16 result bytes; one special of 8 bytes (+ 8 of alignment slack).  Batches are sized from the measured use of every pool.
+constexpr uint64_t POOL_BYTES_PER_NODE = 112 + 60 + 12 + 8 + 8;
 
 // Carves the node and job pools out of [mem, mem + bytes).  No allocation.
 int carve_pools(void *mem, uint64_t bytes, NodePool *np_out, GiPool *gp_out) {
@@ -409,6 +409,7 @@ int carve_pools(void *mem, uint64_t bytes, NodePool *np_out, GiPool *gp_out) {
     gp.job_capacity = static_cast<uint32_t>((cap / 4 * 3) & ~uint64_t(255));
     gp.special_capacity = static_cast<uint32_t>(cap);
     gp.jobs = reinterpret_cast<GiJob *>(take(static_cast<uint64_t>(gp.job_capacity) * sizeof(GiJob)));
+    gp.results = reinterpret_cast<JobResult *>(take(static_cast<uint64_t>(gp.job_capacity) * sizeof(JobResult)));
     gp.specials = reinterpret_cast<GiSpecial *>(take(static_cast<uint64_t>(gp.special_capacity) * sizeof(GiSpecial)));
     if (static_cast<uint64_t>(p - static_cast<char *>(mem)) > bytes) return fail(RT_ERR_NOMEM, "internal: pool carve exceeds budget");
     return RT_OK;

@@ -187,22 +187,29 @@ struct alignas(16) GiJob {
     uint64_t path;      // the parent's RNG path
     uint32_t root;      // camera-ray item
     uint32_t pixel;
-    uint32_t sample_gi;  // bits 0..15 sample index; results of k_trace_gi: bits 16..23 unoccluded rays, bits 24..31 special rays
-    uint32_t first_special;    // result of k_trace_gi
-    uint32_t light_mask;       // point lights (index among the point lights) that get a shadow ray
-    uint32_t shadow_occluded;  // result of k_trace_shadow: the lights of light_mask whose ray was stopped
+    uint32_t sample;
+    uint32_t light_mask;  // point lights (index among the point lights) that get a shadow ray
+    uint32_t _pad[2];
 };
 static_assert(sizeof(GiJob) == 80, "GiJob must be 80 bytes");
+// What the trace kernels leave for k_resolve, apart from the job (16 dense bytes per job: k_resolve reads nothing else of
+// it, and a 16-byte read out of an 80-byte record costs a cache line all the same).
+struct alignas(16) JobResult {
+    uint32_t gi_counts;        // k_trace_gi: bits 0..7 unoccluded rays, bits 8..15 special rays
+    uint32_t first_special;    // k_trace_gi
+    uint32_t shadow_occluded;  // k_trace_shadow: the lights of the job's light_mask whose ray was stopped
+    uint32_t _pad;
+};
 struct GiSpecial {
     uint32_t slot_kind;  // bits 0..30 slot g, bit 31 kind
     uint32_t id;         // kind 0: primitive id (terminal hit, emissive surface); kind 1: node index
 };
 constexpr uint32_t GI_MAX_INPLACE = 64;  // G(d) above a wave's width: the rays are materialised as nodes (the round-1 path)
-constexpr uint32_t job_sample(uint32_t sample_gi) { return sample_gi & 0xFFFFu; }  // constexpr: host and device code alike
-constexpr uint32_t job_unoccluded(uint32_t sample_gi) { return (sample_gi >> 16) & 0xFFu; }
-constexpr uint32_t job_n_special(uint32_t sample_gi) { return sample_gi >> 24; }
+constexpr uint32_t job_unoccluded(uint32_t gi_counts) { return gi_counts & 0xFFu; }  // constexpr: host and device code alike
+constexpr uint32_t job_n_special(uint32_t gi_counts) { return (gi_counts >> 8) & 0xFFu; }
 struct GiPool {
     GiJob *jobs;
+    JobResult *results;  // per job
     GiSpecial *specials;
     uint32_t job_capacity, special_capacity;
 };

@@ -895,7 +895,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
 __device__ __noinline__ RayD gi_draw(const GiJob *job, uint64_t seed, uint32_t slot) {
     const d3 P = mk3(job->P[0], job->P[1], job->P[2]), n = mk3(job->n[0], job->n[1], job->n[2]);
     double u1, u2;
-    rng_pair(seed, job->pixel, job_sample(job->sample_gi), path_child(job->path, SLOT_GI + slot), &u1, &u2);
+    rng_pair(seed, job->pixel, job->sample, path_child(job->path, SLOT_GI + slot), &u1, &u2);
     RayD ray;
     ray.d = sample_direction(SAMPLE_HEMISPHERE, n, 0.0, u1, u2);
     ray.o = P + ray.d * BIAS;  // :115
@@ -1011,10 +1011,9 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
             gp.specials[special_off + static_cast<uint32_t>(__popcll(m_special & below))] =
                 GiSpecial{slot | (wants_node ? 0x80000000u : 0u), wants_node ? node_index : hit_id};
         if (valid && slot == 0) {  // the job's results
-            GiJob &job = gp.jobs[job_index];
-            job.sample_gi = job_sample(job.sample_gi) | (static_cast<uint32_t>(__popcll(m_unocc & job_mask)) << 16) |
-                            (static_cast<uint32_t>(__popcll(m_special & job_mask)) << 24);
-            job.first_special = special_off + static_cast<uint32_t>(__popcll(m_special & ((1ull << (jl * G)) - 1ull)));
+            JobResult &res = gp.results[job_index];
+            res.gi_counts = static_cast<uint32_t>(__popcll(m_unocc & job_mask)) | (static_cast<uint32_t>(__popcll(m_special & job_mask)) << 8);
+            res.first_special = special_off + static_cast<uint32_t>(__popcll(m_special & ((1ull << (jl * G)) - 1ull)));
         }
     }
     // statistics: rays traced here, nodes made here (one atomic pair per wave)
@@ -1186,7 +1185,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
             if (any_hit<COUNT>(sc, tree, stack, ray, dist - BIAS, n_nodes, n_prims)) atomicOr(&s_occ[wbase + p], 1u << want);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the LDS atomics -> the read below
-        if (mask) gp.jobs[first_job + lane].shadow_occluded = s_occ[tid];
+        if (mask) gp.results[first_job + lane].shadow_occluded = s_occ[tid];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // ... before the next round's stores
     }
     if (lane == 0 && wave_rays) atomicAdd(&ctr->shadow_rays, static_cast<unsigned long long>(wave_rays));
@@ -1389,10 +1388,9 @@ __global__ __launch_bounds__(BLOCK, EXPAND_WAVES) void k_expand(SceneDev sc, Wor
             job.path = L.path[tid];
             job.root = L.root[tid];
             job.pixel = L.pixel[tid];
-            job.sample_gi = L.sample[tid];  // the results of k_trace_gi start as zero
-            job.first_special = 0;
+            job.sample = L.sample[tid];
             job.light_mask = mask;
-            job.shadow_occluded = 0;
+            job._pad[0] = job._pad[1] = 0;
             gp.jobs[ji] = job;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // phase A's LDS stores -> phase B's reads (same wave)
@@ -1508,12 +1506,12 @@ __global__ __launch_bounds__(BLOCK, ILLUM ? RESOLVE_ILLUM_WAVES : RESOLVE_WAVES)
             }
 
             uint32_t shadow_occluded = 0;  // the job's other result: the lights of xi.light_mask whose shadow ray was stopped
-            if (!ILLUM && xi.job != NO_JOB) shadow_occluded = gp.jobs[xi.job].shadow_occluded;
+            JobResult jr{};
+            if (!ILLUM && xi.job != NO_JOB) jr = gp.results[xi.job];  // shadow_occluded is valid where the mask is not empty, the GI fields where gi_job
+            if (xi.light_mask) shadow_occluded = jr.shadow_occluded;
             if (gi_job) {  // compute_global_illumination's sums from the job: the non-zero terms in slot order (:121), the count (:123-125)
-                const GiJob &job = gp.jobs[xi.job];
-                const uint32_t res = job.sample_gi;
-                unoccluded = job_unoccluded(res);
-                const uint32_t ns = job_n_special(res), fs = job.first_special;
+                unoccluded = job_unoccluded(jr.gi_counts);
+                const uint32_t ns = job_n_special(jr.gi_counts), fs = jr.first_special;
                 for (uint32_t q = 0; q < ns; ++q) {
                     const GiSpecial sp1 = gp.specials[fs + q];
                     if (sp1.slot_kind >> 31) {  // a node of its own, resolved one level down

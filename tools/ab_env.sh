@@ -3,5 +3,5 @@
 scene=$1; var=$2; shift 2
 for v in "$@"; do
   echo "== $var=$v"
-  env $var=$v timeout -k 10 120 python3 tools/perf_probe.py $scene 24 2>&1 | grep "it2" || exit 1
+  env $var=$v timeout -k 10 120 python3 tools/perf_probe.py $scene 24 2>&1 | grep -E "it1[23]:" || exit 1
 done

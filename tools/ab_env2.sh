@@ -5,6 +5,6 @@ for v in $vals; do
   for s in "$@"; do
     echo -n "== $var=$v $s: "
     if [ "$s" = synthetic ]; then env $var=$v timeout -k 10 300 python3 tools/perf_synth.py 1920 4 2>&1 | grep it2 || exit 1
-    else env $var=$v timeout -k 10 120 python3 tools/perf_probe.py $s 24 2>&1 | grep "it2" | cut -c30-180 || exit 1; fi
+    else env $var=$v timeout -k 10 120 python3 tools/perf_probe.py $s 24 2>&1 | grep -E "it1[23]:" | cut -c30-180 || exit 1; fi
   done
 done
