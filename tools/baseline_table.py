@@ -21,7 +21,7 @@ def bytes_per_ray(kind, nodes, prims, tri_share):
 
 def row(label, scene, cpu_rows):
     g = device.DeviceScene(scene.desc)
-    for _ in range(7):  # first frames: pool sizing, and the library settles its closest-hit switches (six calls at most)
+    for _ in range(12):  # first frames: pool sizing, and the library settles its closest-hit switches (eleven calls at most)
         g.render(want_rgba=False)
     best = None
     for _ in range(3):
@@ -46,9 +46,10 @@ def row(label, scene, cpu_rows):
          "ms": {k: round(getattr(best, "ms_" + k), 2) for k in ("closest", "gi", "illum", "shadow", "expand", "resolve")}, "batches": int(best.batches),
          "gi_variant": "".join(c if best.gi_two_phase >> i & 1 else "-" for i, c in enumerate("ILN")) + f"/{best.gi_waves}w",
          "nodes_per_ray": round(nc, 2), "prims_per_ray": round(pc, 2),
-         "frac_hbm_stream_closest": round(gbs(w.closest_rays * 224.0, ms_hit) / HBM, 3),
+         "launches_overlap": bool(best.overlapped),  # the class times are spans that overlap: no per-class fraction then
+         "frac_hbm_stream_closest": None if best.overlapped else round(gbs(w.closest_rays * 224.0, ms_hit) / HBM, 3),
          "frac_hbm_stream_frame": round(gbs(w.closest_rays * 224.0 + w.shadow_rays * 136.0, best.ms_total) / HBM, 3),
-         "bytes_per_ray_incl_cache": round(bc, 1), "incl_cache_gbs": round(gbs(w.closest_rays * bc, ms_hit), 1),
+         "bytes_per_ray_incl_cache": round(bc, 1), "incl_cache_gbs": None if best.overlapped else round(gbs(w.closest_rays * bc, ms_hit), 1),
          "cpu_mrays": round(n_cpu / dt / 1e6, 2), "cpu_cores": CORES, "cpu_sample": f"rows {y0}..{y0 + cpu_rows} ({n_cpu} rays, {dt:.1f} s)"}
     print(json.dumps(r), flush=True)
     return r
