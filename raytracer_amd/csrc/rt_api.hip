@@ -434,7 +434,9 @@ int ensure_pools(rt_scene *s) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 10 * 8) want = free_b / 10 * 8;
     if (want < (1ull << 20)) return fail(RT_ERR_NOMEM, "less than 1 MiB of device memory free for the wavefront pools");
+    const auto t_alloc = std::chrono::steady_clock::now();
     HIP_TRY(hipMalloc(&s->pool_mem, want));
+    if (std::getenv("MI355RT_TIMING")) std::fprintf(stderr, "[mi355rt] wavefront pools: hipMalloc of %.2f GiB took %.1f ms\n", want / 1073741824.0, Stager::since(t_alloc));
     s->pool_mem_bytes = s->pool_bytes;  // the budget this allocation answers (may be clamped)
     if (int rc = carve_pools(s->pool_mem, want, &ctx.np, &ctx.gp)) return rc;
     ctx.guess_nodes_per_item = s->guess_nodes_per_item;
@@ -1256,19 +1258,20 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
     constexpr uint64_t TUNE_MIN_RAYS = 1000000u;
     const bool gi_tuning = s->gi_tune.exploring() && &ctx == &s->ctx;
     const bool gi_can_qualify = plan.total_items * gi_rays_host(s->dev.opts, 0) >= TUNE_MIN_RAYS && !count_work;
+    const bool gi_warmup = gi_tuning && s->gi_tune.step < 0;  // the scene's first sizeable call: counted, not timed (a one-frame process runs only this)
     EventTimer gi_timer;
-    gi_timer.enabled = gi_tuning && gi_can_qualify && !stats;  // with stats the main timer has the figure
+    gi_timer.enabled = gi_tuning && !gi_warmup && gi_can_qualify && !stats;  // with stats the main timer has the figure
     gi_timer.stream = stream;
     gi_timer.chaining = false;
     // Overlap (rt_scene::Side): where launches have tails worth filling -- a tree too large for LDS / L1 (rays wait on memory:
     // mesh_test.json, 41 K triangles, 10.0 -> 8.4 ms; mesh.json -2 %) or a call of a fraction of a frame (a 1/8 shard of
     // scene.json 3.13 -> 2.99 ms).  A whole frame of a small scene is bound by VALU issue in every one of the three launches
     // and gains nothing (scene.json 17.0 ms either way): it stays on the caller's stream, one kernel at a time.  The scene's
-    // own context only, once its switches are settled (while they are being tried out the closest-hit kernels are timed one
-    // after the other).  MI355RT_OVERLAP=0 / 1 forces either.
+    // own context only, and not while the switches are being tried out (the closest-hit kernels are then timed one after the
+    // other) -- the scene's first call, which the tuner only counts, does overlap: a one-frame process runs nothing else.  MI355RT_OVERLAP=0 / 1 forces either.
     static const char *overlap_env = std::getenv("MI355RT_OVERLAP");
     const bool overlap_wanted = overlap_env ? std::strcmp(overlap_env, "0") != 0 : (s->dev.n_bounded >= 4096 || plan.total_items <= 655360);
-    const bool overlap = overlap_wanted && &ctx == &s->ctx && !gi_tuning && max_depth > 0;
+    const bool overlap = overlap_wanted && &ctx == &s->ctx && (!gi_tuning || gi_warmup) && max_depth > 0;
     if (overlap)
         if ((rc = ensure_side_streams(s))) return rc;
     EventTimer timer_side[2], timer_off;  // spans of the launches on the side streams; timer_off: never enabled
@@ -1502,8 +1505,9 @@ int render_impl(rt_scene *s, RenderCtx &ctx, const rt_render_params *params, dou
         ctx.est_jobs_per_item = call_max[1];
         ctx.est_specials_per_item = call_max[2];
     }
-    if (gi_tuning && !(gi_can_qualify && st.retries == 0 && gi_rays_call >= TUNE_MIN_RAYS && gi_ms > 0.0)) s->gi_tune.skip();
-    if (gi_tuning && gi_can_qualify && st.retries == 0 && gi_rays_call >= TUNE_MIN_RAYS && gi_ms > 0.0) {
+    const bool gi_usable = gi_can_qualify && st.retries == 0 && gi_rays_call >= TUNE_MIN_RAYS && (gi_ms > 0.0 || gi_warmup);
+    if (gi_tuning && !gi_usable) s->gi_tune.skip();
+    if (gi_tuning && gi_usable) {
         GiTune &t = s->gi_tune;
         t.record(gi_cfg, gi_ms / (1e-6 * static_cast<double>(tune_rays_call)));
         if (!t.exploring() && std::getenv("MI355RT_TIMING")) {

@@ -55,10 +55,14 @@ def library(name):
 
 def main():
     out = {"_about": __doc__.split("usage:")[0].strip()}
+    # the fresh processes first, while this one has not touched the GPU (two processes on one GPU take turns: a CLI run beside
+    # this process's HIP context showed stalls of half a second); one discarded run pages the ROCm libraries in from the
+    # fresh box's disk (scene.json as the first process of a box: 215 ms of rt_scene_create instead of 81)
+    cli("test")
+    clis = {name: cli(name) for name in SCENES}
     library("test")  # HIP start-up of this process is not a scene's cost
-    cli("test")      # nor is paging the ROCm libraries in from a fresh box's disk the first process's (scene.json: 215 ms of rt_scene_create instead of 85)
     for name in SCENES:
-        out[name] = {"cli": cli(name), "library": library(name)}
+        out[name] = {"cli": clis[name], "library": library(name)}
         c, l = out[name]["cli"], out[name]["library"]
         print(f"{name:11s} cli: load {c['load_ms']:7.1f} create {c['rt_scene_create_ms']:7.1f} render {c['first_rt_render_ms']:7.1f} (kernels {c['first_rt_render_kernel_ms']:6.1f}) png {c['png_ms']:6.1f} total {c['total_ms']:7.1f} | "
               f"library: first {l['first']['kernel_ms']:7.2f} [{l['first']['switches']}, {l['first']['batches']} batches, {l['first']['retries']} retries] second {l['second']['kernel_ms']:7.2f} "
