@@ -884,10 +884,10 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
 //   specials       in slot order, the rays whose emissive contribution may be non-zero: a terminal hit on an emissive
 //                  surface (its colour is the material's), or a hit that needs get_emissive_* children (:135-167,
 //                  :263-337) -- only that ray gets a node (ray, path, hit; META_TRACED) and joins the level's nodes.
-// WAVES: resident waves per SIMD the register budget is cut for -- 4 (128 VGPRs, some 45 of them spilled: the
-// compiler keeps the sampling routine's f64 constants in registers across the traversal) or 3 (168 VGPRs, 5 spilled).
-// Three are faster where the tree sits in LDS / L2 (scene.json -6 %, cornell_box -12 %), four where its misses need
-// hiding (the 1M-triangle scene +8 % with three); rt_api.hip times both on the scene's first frames.
+// WAVES: resident waves per SIMD the register budget is cut for -- 4 (128 VGPRs, 2 spilled) or 3 (137, none).  Four are
+// faster on every scene measured since the draw became a call and the leaf's box a late load (before: 45 spills at
+// four waves, and three were faster wherever the tree sits in LDS / L2); the tuner still tries three (rt_tune.h).
+// TWO_PHASE: the level's form of query, the host's choice ((sc.gi_two_phase >> set) & 1 and sc.special[set].ok).
 // A GI ray of a job: drawn about the job's normal (the same Philox key and sampler as a stored child would get), :115.
 // A call, not inlined: the sampler's constants and temporaries then end at the call's return instead of staying live
 // across the traversal that follows (the kernel is cut for 128 VGPRs: 43 of them spilled with the draw inlined, 10
