@@ -660,7 +660,7 @@ Shards plan_shards(const RenderCtx &c, uint64_t n, uint32_t ns) {
 uint32_t stack_entries(const rt_scene *s) { return static_cast<uint32_t>(s->bvh_depth + 2); }
 uint32_t stack_lds_bytes(const rt_scene *s) {
     static const uint32_t extra = std::getenv("MI355RT_EXTRA_LDS") ? std::atoi(std::getenv("MI355RT_EXTRA_LDS")) : 0;  // occupancy experiments
-    return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + (s->dev.n_top_nodes + s->dev.special[0].n_top + s->dev.special[1].n_top) * static_cast<uint32_t>(sizeof(BvhNode)) + extra;
+    return static_cast<uint32_t>(s->bvh_depth + 2) * BLOCK * sizeof(uint32_t) + (s->dev.n_top_nodes + s->dev.special[0].n_top + s->dev.special[1].n_top) * TOP_NODE_BYTES + extra;
 }
 
 Shards single_shard(const RenderCtx &c) {
@@ -1081,17 +1081,18 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
     for (int k = 0; k < 9; ++k) dev.cam_to_world[k] = d->camera.cam_to_world[k];
     dev.fov_scale = std::tan(d->camera.fov_deg * (3.14159265358979323846 / 180.0) / 2.0);  // :82-84
     dev.root_ref = bvh.root_ref;
-    {   // top of the tree kept in LDS by the traversal kernels: as many nodes as fit next to the per-lane stacks
-        // without costing a block per CU (four 256-thread blocks share 160 KB), at most 512 (16 KB)
+    {   // top of the trees kept in LDS by the traversal kernels (TOP_NODE_BYTES a node): as many nodes as fit next to the
+        // per-lane stacks without costing a block per CU (four 256-thread blocks share 160 KB) -- the small trees of
+        // the special primitives first (at most 64 nodes each), then the main tree (at most 512)
         const uint32_t stack_bytes = (static_cast<uint32_t>(sc->bvh_depth) + 2u) * BLOCK * static_cast<uint32_t>(sizeof(uint32_t));
         const uint32_t budget = 40u * 1024u - 3072u;  // per block; 3 KB for the kernels' static LDS (work map; k_trace_shadow's prefix sums and result words)
-        const uint32_t fit = stack_bytes < budget ? (budget - stack_bytes) / static_cast<uint32_t>(sizeof(BvhNode)) : 0u;
-        dev.n_top_nodes = static_cast<uint32_t>(std::min<size_t>(n_built_nodes, std::min(fit, 512u)));
-        uint32_t left = fit - dev.n_top_nodes;
+        uint32_t left = stack_bytes < budget ? (budget - stack_bytes) / TOP_NODE_BYTES : 0u;
+        if (const char *e = std::getenv("MI355RT_TOP_NODES")) left = std::min<uint32_t>(left, static_cast<uint32_t>(std::atoi(e)));  // experiments
         for (int q = 0; q < 2; ++q) {
             dev.special[q].n_top = static_cast<uint32_t>(std::min<size_t>(bvh_s[q].nodes.size(), std::min(left, 64u)));
             left -= dev.special[q].n_top;
         }
+        dev.n_top_nodes = static_cast<uint32_t>(std::min<size_t>(n_built_nodes, std::min(left, 512u)));
     }
     for (int q = 0; q < 2; ++q) {
         dev.special[q].root_ref = bvh_s[q].root_ref;

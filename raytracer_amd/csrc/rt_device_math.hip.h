@@ -411,8 +411,8 @@ __device__ __forceinline__ bool hit_bounded(const double *__restrict__ g, uint32
 //     and the rounding of the primitives' reference-order AABB arithmetic in f64;
 //   * inv = 1/d is taken in f32 (v_rcp_f32 of the direction rounded to f32: relative
 //     error <= 1.5 * 2^-23, the same factor on both constants of an axis, so it scales
-//     that axis' distances) and the fma adds 2^-24: entry distances are lowered and
-//     exit distances raised by 2^-21 relative, more than twice what is needed;
+//     that axis' distances) and the fma adds 2^-24: a quarter of P (make_cull_ray has
+//     the whole budget);
 //   * |1/d| is clamped to 1e25, so a ray parallel to a slab (d = +-0) gets
 //     entry/exit distances of magnitude >= 1e25 * P with the right signs, no
 //     inf - inf; comparisons are written so that a NaN (NaN ray) keeps the node.
@@ -430,8 +430,17 @@ __device__ __forceinline__ float cull_inv(double d) {
 // Slab distances are evaluated as fma(q, a, c) with q the 16-bit box coordinate:
 // (q_origin + q q_scale - (o +- P)) / d.  The differences q_origin - (o +- P) are
 // taken in f64 (o is near the box: cancellation) and rounded to f32, the products
-// with 1/d are f32: each rounding displaces the box by <= 2^-24 (scene scale + |o|
-// + P) or 2^-24 of its extent -- P / 4 in all, inside P.
+// with 1/d are f32.  Error budget, in units of a displacement of the slab plane
+// along its axis (S = scene scale + |o|, so P = 2^-20 S):
+//   a = q_scale * inv, rounded:                 <= 2^-24 of the box's extent      (P / 16)
+//   c = f32(difference) * inv, two roundings:   <= 2^-23 S                        (P / 8)
+//   inv = rcp(f32(d)) (1 ulp) and the fma's own rounding: a common factor
+//   1 + e, |e| <= 2^-22, on the axis' distances -- the plane moved by
+//   2^-22 |plane - o| <= 2^-22 S                                                  (P / 4)
+// -- under P / 2 in all.  A ray that meets the true box at t* therefore has, on
+// every axis, a computed entry <= t* <= computed exit: box_cull_test needs no
+// widening of its own beyond P (through round 3 it lowered the entry and raised
+// the exit by another 2^-21 relative: four instructions a node visit for nothing).
 __device__ __forceinline__ CullRay make_cull_ray(const RayD &r, double scene_scale, const float *q_origin, const float *q_scale) {
     const double m = fmax(fmax(fabs(r.o.x), fabs(r.o.y)), fabs(r.o.z));
     const double P = 0x1.0p-20 * (m + scene_scale);
@@ -455,24 +464,22 @@ __device__ __forceinline__ float cull_limit_f32(double t_limit) {
     return f + fabsf(f) * 0x1.0p-21f;  // inf stays inf
 }
 
-// `bmin`/`bmax`: 3 quantised coordinates each.  Returns false when the box can be
-// skipped; *t_entry is the (lowered) entry distance, used to order the children.
+// `bmin`/`bmax`: 3 quantised coordinates each, as f32 (exact).  Returns false when the box can be
+// skipped; *t_entry is the entry distance, used to order the children.
 // Per axis: t1 = (bmin - (o + P)) / d, t2 = (bmax - (o - P)) / d -- whichever of
 // the two is the entry is lowered by P/|d|, the exit raised.
-__device__ __forceinline__ bool box_cull_test(const uint16_t *__restrict__ bmin, const uint16_t *__restrict__ bmax, const CullRay &c,
+__device__ __forceinline__ bool box_cull_test(const float *__restrict__ bmin, const float *__restrict__ bmax, const CullRay &c,
                                               float t_limit, float *t_entry) {
-    float t1 = __builtin_fmaf(static_cast<float>(bmin[0]), c.ax, c.x1), t2 = __builtin_fmaf(static_cast<float>(bmax[0]), c.ax, c.x2);
+    float t1 = __builtin_fmaf(bmin[0], c.ax, c.x1), t2 = __builtin_fmaf(bmax[0], c.ax, c.x2);
     float tn = fminf(t1, t2), tf = fmaxf(t1, t2);
-    t1 = __builtin_fmaf(static_cast<float>(bmin[1]), c.ay, c.y1);
-    t2 = __builtin_fmaf(static_cast<float>(bmax[1]), c.ay, c.y2);
+    t1 = __builtin_fmaf(bmin[1], c.ay, c.y1);
+    t2 = __builtin_fmaf(bmax[1], c.ay, c.y2);
     tn = fmaxf(tn, fminf(t1, t2));
     tf = fminf(tf, fmaxf(t1, t2));
-    t1 = __builtin_fmaf(static_cast<float>(bmin[2]), c.az, c.z1);
-    t2 = __builtin_fmaf(static_cast<float>(bmax[2]), c.az, c.z2);
+    t1 = __builtin_fmaf(bmin[2], c.az, c.z1);
+    t2 = __builtin_fmaf(bmax[2], c.az, c.z2);
     tn = fmaxf(tn, fminf(t1, t2));
     tf = fminf(tf, fmaxf(t1, t2));
-    tn = __builtin_fmaf(-0x1.0p-21f, fabsf(tn), tn);  // lowered (all values are finite)
-    tf = __builtin_fmaf(0x1.0p-21f, fabsf(tf), tf);   // raised
     *t_entry = tn;
     if (tn > tf) return false;
     if (tf < 0.0f) return false;

@@ -577,36 +577,56 @@ __device__ __forceinline__ double cull_limit(double t) { return t + 1e-9 * (1.0 
 
 // The block's copy of the top of the tree (nodes [0, n_top_nodes), breadth-first
 // order) sits in LDS behind the stacks: every ray starts there and most node
-// visits never leave it, which takes them off the vector-memory path that bounds
-// these kernels (two divergent 16-byte loads per visit otherwise).
-__device__ __forceinline__ const uint4 *stage_top_nodes(const SceneDev &sc, uint32_t *stack_lds, uint32_t stack_entries) {
-    uint4 *top = reinterpret_cast<uint4 *>(stack_lds + stack_entries * BLOCK);
-    const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes);
-    for (uint32_t i = threadIdx.x; i < sc.n_top_nodes * 2u; i += BLOCK) top[i] = src[i];
-    uint32_t at = sc.n_top_nodes * 2u;  // the trees of the special primitives behind it
+// visits never leave it, which takes them off the vector-memory path (two
+// divergent 16-byte loads per visit otherwise).  The copy holds the twelve box
+// coordinates ALREADY converted to f32 (64 bytes a node: lmin lmax rmin rmax |
+// left right - -): the conversion of a 16-bit coordinate is exact, so a visit
+// through the copy decides exactly what a visit through memory decides, without
+// the twelve v_cvt a visit (a fifth of the node loop's instructions).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f32x4 LdsNodeWord;
+constexpr uint32_t TOP_NODE_BYTES = 64;
+
+__device__ __forceinline__ void stage_tree_top(const BvhNode *__restrict__ nodes, uint32_t n, float4 *dst) {
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) {
+        const uint4 w0 = reinterpret_cast<const uint4 *>(nodes + i)[0], w1 = reinterpret_cast<const uint4 *>(nodes + i)[1];
+        dst[4u * i + 0u] = make_float4(static_cast<float>(w0.x & 0xFFFFu), static_cast<float>(w0.x >> 16), static_cast<float>(w0.y & 0xFFFFu),
+                                       static_cast<float>(w0.y >> 16));
+        dst[4u * i + 1u] = make_float4(static_cast<float>(w0.z & 0xFFFFu), static_cast<float>(w0.z >> 16), static_cast<float>(w0.w & 0xFFFFu),
+                                       static_cast<float>(w0.w >> 16));
+        dst[4u * i + 2u] = make_float4(static_cast<float>(w1.x & 0xFFFFu), static_cast<float>(w1.x >> 16), static_cast<float>(w1.y & 0xFFFFu),
+                                       static_cast<float>(w1.y >> 16));
+        dst[4u * i + 3u] = make_float4(__uint_as_float(w1.z), __uint_as_float(w1.w), 0.0f, 0.0f);
+    }
+}
+
+__device__ __forceinline__ LdsNodeWord *stage_top_nodes(const SceneDev &sc, uint32_t *stack_lds, uint32_t stack_entries) {
+    float4 *top = reinterpret_cast<float4 *>(stack_lds + stack_entries * BLOCK);
+    stage_tree_top(sc.nodes, sc.n_top_nodes, top);
+    uint32_t at = sc.n_top_nodes;  // the trees of the special primitives behind it
     for (uint32_t q = 0; q < 2; ++q) {
-        const uint4 *src_s = reinterpret_cast<const uint4 *>(sc.special[q].nodes);
-        for (uint32_t i = threadIdx.x; i < sc.special[q].n_top * 2u; i += BLOCK) top[at + i] = src_s[i];
-        at += sc.special[q].n_top * 2u;
+        stage_tree_top(sc.special[q].nodes, sc.special[q].n_top, top + 4u * at);
+        at += sc.special[q].n_top;
     }
     __syncthreads();
-    return top;
+    return (LdsNodeWord *)top;
 }
 
 // One of the scene's trees: all bounded primitives, or one of the two sets of special ones (SceneDev::special).
 struct TreeView {
     const BvhNode *nodes;
     const LeafPrim *leaf_prims;
-    const uint4 *top;  // LDS copy of nodes [0, n_top)
+    LdsNodeWord *top;  // LDS copy of nodes [0, n_top), TOP_NODE_BYTES each
     uint32_t n_top;
     uint32_t root_ref;
 };
-__device__ __forceinline__ TreeView main_tree(const SceneDev &sc, const uint4 *top_nodes) {
+__device__ __forceinline__ TreeView main_tree(const SceneDev &sc, LdsNodeWord *top_nodes) {
     return TreeView{sc.nodes, sc.leaf_prims, top_nodes, sc.n_top_nodes, sc.root_ref};
 }
-__device__ __forceinline__ TreeView special_tree(const SceneDev &sc, const uint4 *top_nodes, uint32_t set) {
+__device__ __forceinline__ TreeView special_tree(const SceneDev &sc, LdsNodeWord *top_nodes, uint32_t set) {
     const SceneDev::SpecialSet &sp = sc.special[set];
-    return TreeView{sp.nodes, sp.leaf_prims, top_nodes + 2u * (sc.n_top_nodes + (set ? sc.special[0].n_top : 0u)), sp.n_top, sp.root_ref};
+    return TreeView{sp.nodes, sp.leaf_prims, top_nodes + 4u * (sc.n_top_nodes + (set ? sc.special[0].n_top : 0u)), sp.n_top, sp.root_ref};
 }
 
 // Descend from `cur` through interior nodes until a leaf ref or the sentinel.
@@ -614,22 +634,33 @@ template <bool COUNT>
 __device__ __forceinline__ uint32_t descend(const TreeView &tv, const CullRay &cr, float limit, uint32_t cur,
                                             uint32_t *stack, uint32_t &sp, unsigned long long &n_nodes) {
     while (!(cur & LEAF_FLAG) && cur != STACK_SENTINEL) {
-        // the 32-byte node (lmin lmax rmin | rmax left right) through a generic pointer: one pair of 16-byte loads
-        // serves the lanes whose node is in LDS and those whose node is in memory
-        const uint4 *nd = cur < tv.n_top ? tv.top + 2u * cur : reinterpret_cast<const uint4 *>(tv.nodes + cur);
-        const uint4 w0 = nd[0], w1 = nd[1];
+        float lmin[3], lmax[3], rmin[3], rmax[3];
+        uint32_t lref, rref;
+        if (cur < tv.n_top) {  // the block's copy: coordinates held as f32
+            LdsNodeWord *nd = tv.top + 4u * cur;
+            const f32x4 a0 = nd[0], a1 = nd[1], a2 = nd[2];
+            const f32x2 a3 = *(__attribute__((address_space(3))) const f32x2 *)(nd + 3);
+            lmin[0] = a0.x, lmin[1] = a0.y, lmin[2] = a0.z, lmax[0] = a0.w, lmax[1] = a1.x, lmax[2] = a1.y;
+            rmin[0] = a1.z, rmin[1] = a1.w, rmin[2] = a2.x, rmax[0] = a2.y, rmax[1] = a2.z, rmax[2] = a2.w;
+            lref = __float_as_uint(a3.x), rref = __float_as_uint(a3.y);
+        } else {  // the 32-byte node in memory (lmin lmax rmin | rmax left right): a pair of 16-byte loads
+            const uint4 *nd = reinterpret_cast<const uint4 *>(tv.nodes + cur);
+            const uint4 w0 = nd[0], w1 = nd[1];
+            lmin[0] = static_cast<float>(static_cast<uint16_t>(w0.x)), lmin[1] = static_cast<float>(static_cast<uint16_t>(w0.x >> 16));
+            lmin[2] = static_cast<float>(static_cast<uint16_t>(w0.y)), lmax[0] = static_cast<float>(static_cast<uint16_t>(w0.y >> 16));
+            lmax[1] = static_cast<float>(static_cast<uint16_t>(w0.z)), lmax[2] = static_cast<float>(static_cast<uint16_t>(w0.z >> 16));
+            rmin[0] = static_cast<float>(static_cast<uint16_t>(w0.w)), rmin[1] = static_cast<float>(static_cast<uint16_t>(w0.w >> 16));
+            rmin[2] = static_cast<float>(static_cast<uint16_t>(w1.x)), rmax[0] = static_cast<float>(static_cast<uint16_t>(w1.x >> 16));
+            rmax[1] = static_cast<float>(static_cast<uint16_t>(w1.y)), rmax[2] = static_cast<float>(static_cast<uint16_t>(w1.y >> 16));
+            lref = w1.z, rref = w1.w;
+        }
         if (COUNT) {  // low 40 bits: lane-level visits; high bits: wave-level visits (counted by the first active lane)
             n_nodes++;
             if ((threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(__ballot(true)) - 1)) n_nodes += 1ull << 40;
         }
-        const uint16_t lmin[3] = {static_cast<uint16_t>(w0.x), static_cast<uint16_t>(w0.x >> 16), static_cast<uint16_t>(w0.y)};
-        const uint16_t lmax[3] = {static_cast<uint16_t>(w0.y >> 16), static_cast<uint16_t>(w0.z), static_cast<uint16_t>(w0.z >> 16)};
-        const uint16_t rmin[3] = {static_cast<uint16_t>(w0.w), static_cast<uint16_t>(w0.w >> 16), static_cast<uint16_t>(w1.x)};
-        const uint16_t rmax[3] = {static_cast<uint16_t>(w1.x >> 16), static_cast<uint16_t>(w1.y), static_cast<uint16_t>(w1.y >> 16)};
         float tl, tr;
         const bool hl = box_cull_test(lmin, lmax, cr, limit, &tl);
         const bool hr = box_cull_test(rmin, rmax, cr, limit, &tr);
-        const uint32_t lref = w1.z, rref = w1.w;
         if (hl && hr) {
             const bool left_first = !(tr < tl);
             stack[(sp++) * BLOCK] = left_first ? rref : lref;
@@ -810,7 +841,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_closest(SceneDev s
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
     const uint32_t n_groups = level_map_build(map, ctrs, shards, level, what);
     if (blockIdx.x * (BLOCK / 64) >= n_groups) return;  // no group for this block: leave before staging the tree (the small launches of the deep levels)
-    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
+    LdsNodeWord *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     unsigned long long n_nodes = 0, n_prims = 0;
     for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
         uint32_t n_valid;
@@ -935,7 +966,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_gi(SceneDev sc, WorkList
     __syncthreads();
     const uint32_t n_groups = map.dead ? 0u : map.prefix[shards.count];
     if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
-    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
+    LdsNodeWord *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const uint32_t lane = threadIdx.x & 63u;
     const bool next_real = level + 1u < sc.opts.max_depth;  // children of this level's hits are traced (else they return zero, :495-497)
     const uint32_t set = next_real ? 0u : 1u;                // which primitives are special on this level
@@ -1041,7 +1072,7 @@ __global__ __launch_bounds__(BLOCK, WAVES) void k_trace_illum_last(SceneDev sc, 
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
     const uint32_t n_groups = level_map_build(map, ctrs, shards, level, what);
     if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
-    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
+    LdsNodeWord *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     unsigned long long n_nodes = 0, n_prims = 0;
     uint32_t wave_rays = 0;
     for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
@@ -1142,7 +1173,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow(SceneDev sc
     Counters *ctr = ctrs + blockIdx.x % shards.count;  // statistics only
     const uint32_t n_groups = level_map_build(map, ctrs, shards, level, what);  // MAP_JOBS: all levels at once; MAP_LEVEL_JOBS: the jobs of `level`
     if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
-    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
+    LdsNodeWord *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     const TreeView tree = main_tree(sc, top_nodes);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wbase = tid & ~63u;
     unsigned long long n_nodes = 0, n_prims = 0;
@@ -1201,7 +1232,7 @@ __global__ __launch_bounds__(BLOCK, TRACE_WAVES) void k_trace_shadow_probe(Scene
     uint32_t *stack = stack_lds + threadIdx.x;
     const uint32_t n_groups = (probe_count + 63u) / 64u;
     if (blockIdx.x * (BLOCK / 64) >= n_groups) return;
-    const uint4 *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
+    LdsNodeWord *top_nodes = stage_top_nodes(sc, stack_lds, stack_entries);
     unsigned long long n_nodes = 0, n_prims = 0;
     for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); g < n_groups; g += gridDim.x * (BLOCK / 64)) {
         const uint32_t i = g * 64u + (threadIdx.x & 63u);
