@@ -1087,7 +1087,7 @@ int scene_create_impl(const rt_scene_desc *d, rt_scene **out) {
         const uint32_t stack_bytes = (static_cast<uint32_t>(sc->bvh_depth) + 2u) * BLOCK * static_cast<uint32_t>(sizeof(uint32_t));
         const uint32_t budget = 40u * 1024u - 3072u;  // per block; 3 KB for the kernels' static LDS (work map; k_trace_shadow's prefix sums and result words)
         uint32_t left = stack_bytes < budget ? (budget - stack_bytes) / TOP_NODE_BYTES : 0u;
-        if (const char *e = std::getenv("MI355RT_TOP_NODES")) left = std::min<uint32_t>(left, static_cast<uint32_t>(std::atoi(e)));  // experiments
+        if (const char *e = std::getenv("MI355RT_TOP_NODES")) left = std::min<uint32_t>(left, static_cast<uint32_t>(std::atoi(e)));  // experiments; tests/test_lds_top.py
         for (int q = 0; q < 2; ++q) {
             dev.special[q].n_top = static_cast<uint32_t>(std::min<size_t>(bvh_s[q].nodes.size(), std::min(left, 64u)));
             left -= dev.special[q].n_top;
